@@ -1,0 +1,93 @@
+"""ctypes binding of libconmamba_hip.so (C ABI: include/conmamba_hip.h).
+
+The library is built in-tree (``mamba-asr_amd/lib/libconmamba_hip.so``) by
+``__graft_entry__.build()`` / ``make -C mamba-asr_amd/csrc``.  There is no CPU fallback:
+if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libconmamba_hip.so")
+
+CM_F32, CM_BF16, CM_F16 = 0, 1, 2
+CM_SCAN_CHUNK = 64
+ABI_VERSION = 1
+
+i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
+
+
+class ScanFwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("seqlen", i32), ("dstate", i32),
+        ("io_dtype", i32), ("bc_dtype", i32), ("delta_softplus", i32), ("reverse_time", i32),
+        ("u", vp), ("delta", vp), ("A", fp), ("B", vp), ("C", vp), ("D", fp), ("z", vp), ("delta_bias", fp),
+        ("out", vp), ("out_z", vp), ("x", fp),
+        ("u_bs", i64), ("u_ds", i64), ("delta_bs", i64), ("delta_ds", i64), ("z_bs", i64), ("z_ds", i64),
+        ("out_bs", i64), ("out_ds", i64), ("B_bs", i64), ("B_ns", i64), ("C_bs", i64), ("C_ns", i64),
+        ("stream", vp),
+    ]
+
+
+class ScanBwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", ScanFwdArgs),
+        ("dout", vp), ("dout_bs", i64), ("dout_ds", i64),
+        ("du", vp), ("ddelta", vp), ("dz", vp),
+        ("du_bs", i64), ("du_ds", i64), ("ddelta_bs", i64), ("ddelta_ds", i64), ("dz_bs", i64), ("dz_ds", i64),
+        ("dA", fp), ("dB", fp), ("dC", fp), ("dD", fp), ("ddelta_bias", fp),
+    ]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("seqlen", i32), ("width", i32),
+        ("io_dtype", i32), ("silu", i32), ("reverse_time", i32),
+        ("x", vp), ("weight", fp), ("bias", fp), ("y", vp),
+        ("x_bs", i64), ("x_ds", i64), ("y_bs", i64), ("y_ds", i64),
+        ("dy", vp), ("dx", vp), ("dweight", fp), ("dbias", fp),
+        ("dy_bs", i64), ("dy_ds", i64), ("dx_bs", i64), ("dx_ds", i64),
+        ("stream", vp),
+    ]
+
+
+# every symbol include/conmamba_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("cm_abi_version", C.c_int, []),
+    ("cm_last_error", C.c_char_p, []),
+    ("cm_scan_num_chunks", C.c_int, [C.c_int]),
+    ("cm_scan_set_split", C.c_int, [C.c_int]),
+    ("cm_selective_scan_fwd", C.c_int, [C.POINTER(ScanFwdArgs)]),
+    ("cm_selective_scan_bwd", C.c_int, [C.POINTER(ScanBwdArgs)]),
+    ("cm_causal_conv1d_fwd", C.c_int, [C.POINTER(ConvArgs)]),
+    ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
+]
+
+_lib = None
+
+
+def lib():
+    """dlopen the HIP library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mamba-asr_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(handle, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        got = handle.cm_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libconmamba_hip ABI {got} != binding {ABI_VERSION}: rebuild the library")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().cm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,112 @@
+// cm_common.h — shared host/device helpers for libconmamba_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/conmamba_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// host side: error reporting
+// ---------------------------------------------------------------------------------------
+void cm_set_error(const char *fmt, ...);
+
+#define CM_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            cm_set_error(__VA_ARGS__);         \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+static inline int cm_launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cm_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return CM_OK;
+}
+
+static inline bool cm_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------
+#define CM_LOG2E 1.4426950408889634f
+#define CM_LN2   0.6931471805599453f
+
+typedef uint16_t cm_bf16_raw;   // storage type of bf16
+typedef uint16_t cm_f16_raw;
+
+template <typename T> struct cm_elem;   // io element traits
+template <> struct cm_elem<float> {
+    static constexpr int kVec = 4;   // elements per 16-byte vector
+    static __device__ __forceinline__ float load(const float *p) { return *p; }
+    static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+};
+struct cm_bf16 { uint16_t bits; };
+struct cm_f16 { uint16_t bits; };
+template <> struct cm_elem<cm_bf16> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ float from_bits(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+    static __device__ __forceinline__ uint16_t to_bits(float v) {
+        __bf16 b = static_cast<__bf16>(v);       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        return __builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ __forceinline__ float load(const cm_bf16 *p) { return from_bits(p->bits); }
+    static __device__ __forceinline__ void store(cm_bf16 *p, float v) { p->bits = to_bits(v); }
+};
+template <> struct cm_elem<cm_f16> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ float from_bits(uint16_t b) { return static_cast<float>(__builtin_bit_cast(_Float16, b)); }
+    static __device__ __forceinline__ uint16_t to_bits(float v) {
+        _Float16 h = static_cast<_Float16>(v);
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ float load(const cm_f16 *p) { return from_bits(p->bits); }
+    static __device__ __forceinline__ void store(cm_f16 *p, float v) { p->bits = to_bits(v); }
+};
+
+__device__ __forceinline__ float cm_bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float cm_bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp)
+__device__ __forceinline__ float cm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float cm_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float cm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float cm_sigmoid(float x) { return cm_rcp(1.0f + cm_exp2(-CM_LOG2E * x)); }
+// softplus, beta=1, threshold=20 (torch default; reference selective_scan_interface.py:112).
+// For x < -15, log1p(e^x) == e^x to fp32 precision; using it avoids the 1+tiny cancellation.
+__device__ __forceinline__ float cm_softplus(float x) {
+    float ex = cm_exp2(CM_LOG2E * x);
+    float sp = CM_LN2 * cm_log2(1.0f + ex);
+    sp = x < -15.0f ? ex : sp;
+    return x > 20.0f ? x : sp;
+}
+
+// DPP helpers (full-rate cross-lane moves inside a row of 16 lanes)
+template <int CTRL> __device__ __forceinline__ float cm_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#define CM_DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define CM_DPP_ROW_HALF_MIRROR 0x141
+#define CM_DPP_ROW_MIRROR 0x140
+
+// sum over groups of S adjacent lanes (S in {1,2,4,8,16}); every lane of the group gets the sum
+template <int S> __device__ __forceinline__ float cm_group_sum(float v) {
+    if constexpr (S >= 2) v += cm_dpp<CM_DPP_QUAD(1, 0, 3, 2)>(v);
+    if constexpr (S >= 4) v += cm_dpp<CM_DPP_QUAD(2, 3, 0, 1)>(v);
+    if constexpr (S >= 8) v += cm_dpp<CM_DPP_ROW_HALF_MIRROR>(v);
+    if constexpr (S >= 16) v += cm_dpp<CM_DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+// broadcast from lane K of each group of Q adjacent lanes (Q in {1,2,4})
+template <int Q, int K> __device__ __forceinline__ float cm_group_bcast(float v) {
+    if constexpr (Q == 1) return v;
+    else if constexpr (Q == 2) return cm_dpp<CM_DPP_QUAD(K, K, 2 + K, 2 + K)>(v);
+    else return cm_dpp<CM_DPP_QUAD(K, K, K, K)>(v);
+}

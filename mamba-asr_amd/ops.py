@@ -1,0 +1,182 @@
+"""Tensor-level wrappers over the C ABI (include/conmamba_hip.h).
+
+These play the role of the reference's binary extension modules
+``selective_scan_cuda`` / ``causal_conv1d_cuda`` (reference
+modules/mamba/selective_scan_interface.py:15-16): torch tensors in, torch tensors out, all
+arithmetic in the HIP library.  PyTorch is used for device memory and the stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+_DT = {torch.float32: N.CM_F32, torch.bfloat16: N.CM_BF16, torch.float16: N.CM_F16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev_check(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mamba_asr_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _time_contig(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    # same rule as the reference wrappers (selective_scan_interface.py:24-35): last dim must have stride 1
+    if t is None:
+        return None
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def num_chunks(seqlen: int) -> int:
+    return (seqlen + N.CM_SCAN_CHUNK - 1) // N.CM_SCAN_CHUNK
+
+
+def _bc4(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() == 3:
+        t = t.unsqueeze(1)
+    if t.dim() != 4 or t.shape[1] != 1:
+        raise RuntimeError("B/C must be (batch, dstate, seqlen) or (batch, 1, dstate, seqlen): one group only")
+    return _time_contig(t)
+
+
+def _fill_scan_args(a, u, delta, A, B, C_, D, z, delta_bias, delta_softplus, reverse):
+    b, d, l = u.shape
+    a.batch, a.dim, a.seqlen, a.dstate = b, d, l, A.shape[1]
+    a.io_dtype, a.bc_dtype = _DT[u.dtype], _DT[B.dtype]
+    a.delta_softplus, a.reverse_time = int(bool(delta_softplus)), int(bool(reverse))
+    a.u, a.delta, a.A, a.B, a.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C_)
+    a.D, a.z, a.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
+    a.u_bs, a.u_ds = u.stride(0), u.stride(1)
+    a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
+    if z is not None:
+        a.z_bs, a.z_ds = z.stride(0), z.stride(1)
+    a.B_bs, a.B_ns = B.stride(0), B.stride(2)
+    a.C_bs, a.C_ns = C_.stride(0), C_.stride(2)
+    a.stream = _stream()
+
+
+def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                       reverse=False, need_out=True, need_x=True):
+    """-> (out, x, out_z): what selective_scan_cuda.fwd returns (selective_scan_interface.py:42).
+    ``out`` is the pre-gate output (None when z is given and need_out is False), ``x`` the
+    checkpoint tensor (batch, dim, nchunks, 2*dstate) or None, ``out_z`` the gated output or None."""
+    _dev_check(u, delta, A, B, C, D, z, delta_bias)
+    u, delta, z = _time_contig(u), _time_contig(delta), _time_contig(z)
+    if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
+        raise RuntimeError("u, delta and z must share one dtype")
+    B, C = _bc4(B), _bc4(C)
+    if B.dtype != C.dtype:
+        raise RuntimeError("B and C must share one dtype")
+    A, D, delta_bias = _f32c(A), _f32c(D), _f32c(delta_bias)
+    b, d, l = u.shape
+    a = N.ScanFwdArgs()
+    _fill_scan_args(a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse)
+    out = torch.empty((b, d, l), dtype=u.dtype, device=u.device) if (z is None or need_out) else None
+    out_z = torch.empty((b, d, l), dtype=u.dtype, device=u.device) if z is not None else None
+    x = torch.empty((b, d, num_chunks(l), 2 * A.shape[1]), dtype=torch.float32, device=u.device) if need_x else None
+    a.out, a.out_z, a.x = _ptr(out), _ptr(out_z), _ptr(x)
+    a.out_bs, a.out_ds = d * l, l
+    N.check(N.lib().cm_selective_scan_fwd(C.byref(a)), "cm_selective_scan_fwd")
+    return out, x, out_z
+
+
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softplus=False, reverse=False,
+                       dz: Optional[torch.Tensor] = None, recompute_out_z=False):
+    """-> (du, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z): the tuple selective_scan_cuda.bwd
+    returns (selective_scan_interface.py:67, 252).  ``dz`` may be a pre-allocated view (e.g. half of
+    dxz, :249-256).  dB/dC are fp32 (batch, 1, dstate, seqlen)."""
+    _dev_check(u, delta, A, B, C, D, z, delta_bias, dout, x)
+    u, delta, z, dout = _time_contig(u), _time_contig(delta), _time_contig(z), _time_contig(dout)
+    B, C = _bc4(B), _bc4(C)
+    A, D, delta_bias = _f32c(A), _f32c(D), _f32c(delta_bias)
+    b, d, l = u.shape
+    n = A.shape[1]
+    a = N.ScanBwdArgs()
+    _fill_scan_args(a.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse)
+    if x is None:
+        raise RuntimeError("selective_scan_bwd needs the forward's checkpoint tensor x")
+    a.fwd.x = _ptr(x)
+    out_z = None
+    if z is not None and recompute_out_z:
+        out_z = torch.empty((b, d, l), dtype=u.dtype, device=u.device)
+        a.fwd.out_z, a.fwd.out_bs, a.fwd.out_ds = _ptr(out_z), d * l, l
+    dev = u.device
+    du = torch.empty((b, d, l), dtype=u.dtype, device=dev)
+    ddelta = torch.empty((b, d, l), dtype=u.dtype, device=dev)
+    if z is not None and dz is None:
+        dz = torch.empty((b, d, l), dtype=u.dtype, device=dev)
+    if z is not None and dz.stride(-1) != 1:
+        raise RuntimeError("dz must be time-contiguous")
+    dA = torch.zeros((d, n), dtype=torch.float32, device=dev)
+    dB = torch.zeros((b, 1, n, l), dtype=torch.float32, device=dev)
+    dC = torch.zeros((b, 1, n, l), dtype=torch.float32, device=dev)
+    dD = torch.zeros((d,), dtype=torch.float32, device=dev) if D is not None else None
+    dbias = torch.zeros((d,), dtype=torch.float32, device=dev) if delta_bias is not None else None
+    a.dout, a.dout_bs, a.dout_ds = _ptr(dout), dout.stride(0), dout.stride(1)
+    a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz if z is not None else None)
+    a.du_bs, a.du_ds, a.ddelta_bs, a.ddelta_ds = d * l, l, d * l, l
+    if z is not None:
+        a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
+    a.dA, a.dB, a.dC, a.dD, a.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias)
+    N.check(N.lib().cm_selective_scan_bwd(C.byref(a)), "cm_selective_scan_bwd")
+    return du, ddelta, dA, dB, dC, dD, dbias, (dz if z is not None else None), out_z
+
+
+def causal_conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, out: Optional[torch.Tensor] = None):
+    """x (batch, dim, seqlen), weight (dim, width) -> y.  causal_conv1d_cuda.causal_conv1d_fwd
+    (selective_scan_interface.py:182) with seq_idx=None."""
+    _dev_check(x, weight, bias)
+    x = _time_contig(x)
+    w, bs = _f32c(weight), _f32c(bias)
+    b, d, l = x.shape
+    y = out if out is not None else torch.empty((b, d, l), dtype=x.dtype, device=x.device)
+    a = N.ConvArgs()
+    a.batch, a.dim, a.seqlen, a.width = b, d, l, w.shape[1]
+    a.io_dtype, a.silu, a.reverse_time = _DT[x.dtype], int(bool(silu)), int(bool(reverse))
+    a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(w), _ptr(bs), _ptr(y)
+    a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
+    a.stream = _stream()
+    N.check(N.lib().cm_causal_conv1d_fwd(C.byref(a)), "cm_causal_conv1d_fwd")
+    return y
+
+
+def causal_conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx: Optional[torch.Tensor] = None):
+    """-> (dx, dweight (dim, width) fp32, dbias (dim) fp32 or None); dx may be a pre-allocated view
+    (selective_scan_interface.py:286-288)."""
+    _dev_check(x, weight, bias, dy, dx)
+    x, dy = _time_contig(x), _time_contig(dy)
+    w, bs = _f32c(weight), _f32c(bias)
+    b, d, l = x.shape
+    if dx is None:
+        dx = torch.empty((b, d, l), dtype=x.dtype, device=x.device)
+    if dx.stride(-1) != 1:
+        raise RuntimeError("dx must be time-contiguous")
+    dw = torch.zeros_like(w)
+    db = torch.zeros((d,), dtype=torch.float32, device=x.device) if bias is not None else None
+    a = N.ConvArgs()
+    a.batch, a.dim, a.seqlen, a.width = b, d, l, w.shape[1]
+    a.io_dtype, a.silu, a.reverse_time = _DT[x.dtype], int(bool(silu)), int(bool(reverse))
+    a.x, a.weight, a.bias = _ptr(x), _ptr(w), _ptr(bs)
+    a.x_bs, a.x_ds = x.stride(0), x.stride(1)
+    a.dy, a.dx, a.dweight, a.dbias = _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db)
+    a.dy_bs, a.dy_ds, a.dx_bs, a.dx_ds = dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1)
+    a.stream = _stream()
+    N.check(N.lib().cm_causal_conv1d_bwd(C.byref(a)), "cm_causal_conv1d_bwd")
+    return dx, dw, db

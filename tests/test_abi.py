@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/conmamba_hip.h declares; argument validation works without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import mamba_asr_amd._native as N
+    if not os.path.exists(N.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "mamba-asr_amd", "csrc")])
+    return N
+
+
+def test_header_symbols_exported(native):
+    hdr = open(os.path.join(ROOT, "include", "conmamba_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char \*)\s*\*?\s*(cm_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert {"cm_selective_scan_fwd", "cm_selective_scan_bwd", "cm_causal_conv1d_fwd", "cm_causal_conv1d_bwd",
+            "cm_abi_version", "cm_last_error", "cm_scan_num_chunks", "cm_scan_set_split"} <= declared
+    handle = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in conmamba_hip.h but not exported"
+    assert {s[0] for s in native.SYMBOLS} == declared
+
+
+def test_abi_version_and_chunks(native):
+    lib = native.lib()
+    assert lib.cm_abi_version() == native.ABI_VERSION
+    assert lib.cm_scan_num_chunks(1) == 1
+    assert lib.cm_scan_num_chunks(64) == 1
+    assert lib.cm_scan_num_chunks(65) == 2
+
+
+def test_bad_arguments_are_rejected_not_fatal(native):
+    lib = native.lib()
+    a = native.ScanFwdArgs()          # all zero: sizes invalid
+    rc = lib.cm_selective_scan_fwd(C.byref(a))
+    assert rc == -1
+    assert b"bad sizes" in lib.cm_last_error()
+    a.batch, a.dim, a.seqlen, a.dstate = 1, 8, 16, 16
+    rc = lib.cm_selective_scan_fwd(C.byref(a))   # null pointers
+    assert rc == -1 and b"non-NULL" in lib.cm_last_error()
+    assert lib.cm_selective_scan_fwd(None) == -1
+    c = native.ConvArgs()
+    assert lib.cm_causal_conv1d_fwd(C.byref(c)) == -1
+    b = native.ScanBwdArgs()
+    assert lib.cm_selective_scan_bwd(C.byref(b)) == -1
+
+
+def test_ops_refuse_cpu_tensors(native):
+    import torch
+    from mamba_asr_amd import ops
+    x = torch.zeros(1, 8, 16)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.causal_conv1d_fwd(x, torch.zeros(8, 4))

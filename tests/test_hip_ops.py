@@ -1,0 +1,177 @@
+"""GPU parity tests of the native ops, called through the C ABI (mamba_asr_amd.ops), against
+ (a) the golden vectors produced by the reference's own Python and (b) the CPU oracle on seeded
+inputs.  Tolerances: fp32 I/O rtol 2e-4 / atol 5e-5 on forward results (v_exp_f32 / v_log_f32 are
+~1 ulp, the recurrence accumulates over seqlen); bf16 I/O within 2 bf16 ulps (rtol 1.6e-2)."""
+import pytest
+import torch
+
+from oracle import conmamba_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a.detach().double().cpu(), b.detach().double().cpu(), rtol=rtol, atol=atol)
+
+
+def gpu(*ts):
+    return [None if t is None else t.to(DEV) for t in ts]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mamba_asr_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid", "long", "n8"])
+@pytest.mark.parametrize("split", [0, 1, 2, 4, 8, 16])
+def test_scan_fwd_golden(ops, golden, tag, split):
+    g = golden("g1_scan_fwd")
+    u, dl, A, B, C, D, z, bias = gpu(*[g[f"{tag}_{k}"] for k in ("u", "delta", "A", "B", "C", "D", "z", "bias")])
+    if split > A.shape[1]:
+        pytest.skip("split larger than dstate")
+    from mamba_asr_amd import _native
+    prev = _native.lib().cm_scan_set_split(split)        # 0 = automatic choice
+    try:
+        out, x, out_z = ops.selective_scan_fwd(u, dl, A, B, C, D, z, bias, True)
+    finally:
+        _native.lib().cm_scan_set_split(prev)
+    close(out_z, g[f"{tag}_out_full"], 2e-4, 5e-5)
+    close(x[:, :, -1, 1::2], g[f"{tag}_last_full"], 2e-4, 5e-5)       # ssi.py:45 contract
+    close(out * torch.nn.functional.silu(z), g[f"{tag}_out_full"], 2e-4, 5e-5)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_scan_fwd_variants(ops, golden, tag):
+    g = golden("g1_scan_fwd")
+    u, dl, A, B, C, D, z, bias = gpu(*[g[f"{tag}_{k}"] for k in ("u", "delta", "A", "B", "C", "D", "z", "bias")])
+    t = (2e-4, 5e-5)
+    close(ops.selective_scan_fwd(u, dl, A, B, C, D, None, bias, True)[0], g[f"{tag}_out_noz"], *t)
+    close(ops.selective_scan_fwd(u, dl, A, B, C, None, z, bias, True)[2], g[f"{tag}_out_noD"], *t)
+    close(ops.selective_scan_fwd(u, dl, A, B, C, D, z, None, True)[2], g[f"{tag}_out_nobias"], *t)
+    close(ops.selective_scan_fwd(u, dl.abs() * 0.1, A, B, C, D, z, None, False)[2], g[f"{tag}_out_nosoftplus"], *t)
+    close(ops.selective_scan_fwd(u, dl, A, B, C, None, None, None, True)[0], g[f"{tag}_out_bare"], *t)
+    close(ops.selective_scan_fwd(u, dl, A, B[:, None], C[:, None], D, z, bias, True)[2], g[f"{tag}_out_4d"], *t)
+    # reverse_time flag == flip inputs, scan, flip output (reference bimamba.py:237,253)
+    close(ops.selective_scan_fwd(u, dl, A, B, C, D, z, bias, True, reverse=True)[2], g[f"{tag}_out_rev"], *t)
+    bf = lambda v: v.to(torch.bfloat16)
+    ob = ops.selective_scan_fwd(bf(u), bf(dl), A, bf(B), bf(C), D, bf(z), bias, True)[2]
+    assert ob.dtype == torch.bfloat16
+    close(ob.float(), g[f"{tag}_out_bf16"], 1.6e-2, 1e-2)
+    # bf16 activations with fp32 B/C (the fused path keeps x_dbl in fp32)
+    ob2 = ops.selective_scan_fwd(bf(u), bf(dl), A, bf(B).float(), bf(C).float(), D, bf(z), bias, True)[2]
+    close(ob2.float(), g[f"{tag}_out_bf16"], 1.6e-2, 1e-2)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 1, 16), (3, 70, 129, 16), (2, 64, 64, 16), (1, 288, 251, 16), (2, 16, 40, 8)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_scan_fwd_vs_oracle_ragged(ops, shape, reverse):
+    """odd sizes: channel counts that do not fill a workgroup, seqlen not a multiple of the vector
+    width (unaligned element-wise path), single step."""
+    b, e, l, n = shape
+    gen = torch.Generator().manual_seed(1234 + l)
+    u = torch.randn(b, e, l, generator=gen)
+    dl = torch.randn(b, e, l, generator=gen) * 0.5
+    A = -torch.exp(torch.randn(e, n, generator=gen) * 0.3)
+    B, C = torch.randn(b, n, l, generator=gen), torch.randn(b, n, l, generator=gen)
+    D, z, bias = torch.randn(e, generator=gen), torch.randn(b, e, l, generator=gen), torch.randn(e, generator=gen) - 1
+    f = (lambda t: t.flip(-1)) if reverse else (lambda t: t)
+    ref, last = O.selective_scan(f(u), f(dl), A, f(B), f(C), D, f(z), bias, True, True, work_dtype=torch.float64)
+    ref = f(ref)
+    out, x, out_z = ops.selective_scan_fwd(*gpu(u, dl, A, B, C, D, z, bias), True, reverse=reverse)
+    close(out_z, ref, 2e-4, 5e-5)
+    close(x[:, :, 0 if reverse else -1, 1::2], last, 2e-4, 5e-5)
+
+
+def test_scan_fwd_strided_xz_views(ops):
+    """u/z as the two halves of one xz tensor (reference ssi.py:180) — dim/batch strides honoured."""
+    gen = torch.Generator().manual_seed(7)
+    b, e, l, n = 2, 32, 96, 16
+    xz = torch.randn(b, 2 * e, l, generator=gen).to(DEV)
+    u, z = xz.chunk(2, dim=1)
+    dl = (torch.randn(b, e, l, generator=gen) * 0.5).to(DEV)
+    A = -torch.rand(e, n, generator=gen).to(DEV) - 0.1
+    B, C = torch.randn(b, n, l, generator=gen).to(DEV), torch.randn(b, n, l, generator=gen).to(DEV)
+    got = ops.selective_scan_fwd(u, dl, A, B, C, None, z, None, True)[2]
+    ref = O.selective_scan(u.cpu(), dl.cpu(), A.cpu(), B.cpu(), C.cpu(), None, z.cpu(), None, True, work_dtype=torch.float64)
+    close(got, ref, 2e-4, 5e-5)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid", "long"])
+def test_scan_bwd_golden(ops, golden, tag):
+    g = golden("g2_scan_bwd")
+    u, dl, A, B, C, D, z, bias, dout = gpu(*[g[f"{tag}_{k}"] for k in ("u", "delta", "A", "B", "C", "D", "z", "bias", "dout")])
+    _, x, out_z = ops.selective_scan_fwd(u, dl, A, B, C, D, z, bias, True, need_out=False)
+    du, dd, dA, dB, dC, dD, dbias, dz, oz = ops.selective_scan_bwd(u, dl, A, B, C, D, z, bias, dout, x, True,
+                                                                   recompute_out_z=True)
+    close(oz, g[f"{tag}_out"], 2e-4, 5e-5)
+    for got, key in ((du, "du"), (dd, "ddelta"), (dA, "dA"), (dB[:, 0], "dB"), (dC[:, 0], "dC"), (dD, "dD"),
+                     (dz, "dz"), (dbias, "dbias")):
+        ref = g[f"{tag}_{key}"]
+        close(got, ref, 3e-3, 3e-4 * max(ref.abs().max().item(), 1.0))
+    if tag == "tiny":
+        _, x, _ = ops.selective_scan_fwd(u, dl, A, B, C, None, None, None, True)
+        r = ops.selective_scan_bwd(u, dl, A, B, C, None, None, None, dout, x, True)
+        for got, key in ((r[0], "du"), (r[1], "ddelta"), (r[2], "dA"), (r[3][:, 0], "dB"), (r[4][:, 0], "dC")):
+            ref = g[f"tiny_bare_{key}"]
+            close(got, ref, 3e-3, 3e-4 * max(ref.abs().max().item(), 1.0))
+        assert r[5] is None and r[6] is None and r[7] is None
+
+
+@pytest.mark.parametrize("shape", [(2, 70, 129, 16), (1, 8, 3, 16), (2, 16, 200, 8)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_scan_bwd_vs_oracle(ops, shape, reverse):
+    b, e, l, n = shape
+    gen = torch.Generator().manual_seed(99 + l)
+    u = torch.randn(b, e, l, generator=gen)
+    dl = torch.randn(b, e, l, generator=gen) * 0.5
+    A = -torch.exp(torch.randn(e, n, generator=gen) * 0.3)
+    B, C = torch.randn(b, n, l, generator=gen), torch.randn(b, n, l, generator=gen)
+    D, z, bias = torch.randn(e, generator=gen), torch.randn(b, e, l, generator=gen), torch.randn(e, generator=gen) - 1
+    dout = torch.randn(b, e, l, generator=gen)
+    f = (lambda t: t.flip(-1)) if reverse else (lambda t: t)
+    r = O.selective_scan_bwd(f(u), f(dl), A, f(B), f(C), D, f(z), bias, f(dout), True)
+    gu, gdl, gA, gB, gC, gD, gz, gbias, gdout = gpu(u, dl, A, B, C, D, z, bias, dout)
+    _, x, _ = ops.selective_scan_fwd(gu, gdl, gA, gB, gC, gD, gz, gbias, True, reverse=reverse, need_out=False)
+    du, dd, dA, dB, dC, dD, dbias, dz, _ = ops.selective_scan_bwd(gu, gdl, gA, gB, gC, gD, gz, gbias, gdout, x, True,
+                                                                  reverse=reverse)
+    for got, ref in ((du, f(r["du"])), (dd, f(r["ddelta"])), (dA, r["dA"]), (dB[:, 0], f(r["dB"])),
+                     (dC[:, 0], f(r["dC"])), (dD, r["dD"]), (dz, f(r["dz"])), (dbias, r["ddelta_bias"])):
+        close(got, ref, 2e-3, 2e-4 * max(ref.abs().max().item(), 1.0))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid", "w3", "short"])
+def test_conv_golden(ops, golden, tag):
+    g = golden("k_conv")
+    x, w, b, dout = gpu(g[f"{tag}_x"], g[f"{tag}_w"], g[f"{tag}_b"], g[f"{tag}_dout"])
+    close(ops.causal_conv1d_fwd(x, w, b, True), g[f"{tag}_y"], 1e-5, 1e-5)
+    close(ops.causal_conv1d_fwd(x, w, None, False), g[f"{tag}_y_lin"], 1e-5, 1e-5)
+    dx, dw, db = ops.causal_conv1d_bwd(x, w, b, dout, True)
+    close(dx, g[f"{tag}_dx"], 1e-4, 1e-5)
+    close(dw, g[f"{tag}_dw"], 1e-4, 1e-4)
+    close(db, g[f"{tag}_db"], 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("l", [64, 251])
+def test_conv_reverse_and_strided(ops, dtype, l):
+    gen = torch.Generator().manual_seed(5)
+    xz = torch.randn(2, 96, l, generator=gen).to(dtype).to(DEV)
+    x = xz[:, :48]
+    w, b = torch.randn(48, 4, generator=gen).to(DEV), torch.randn(48, generator=gen).to(DEV)
+    ref = O.causal_conv1d(x.cpu().float().flip(-1), w.cpu(), b.cpu(), True, work_dtype=torch.float64).flip(-1)
+    got = ops.causal_conv1d_fwd(x, w, b, True, reverse=True)
+    tol = (1e-5, 1e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
+    close(got.float(), ref, *tol)
+    dy = torch.randn(2, 48, l, generator=gen).to(dtype).to(DEV)
+    dxz = torch.zeros_like(xz)
+    dx, dw, db = ops.causal_conv1d_bwd(x, w, b, dy, True, reverse=True, dx=dxz[:, :48])
+    rdx, rdw, rdb = O.causal_conv1d_bwd(x.cpu().float().flip(-1), w.cpu(), b.cpu(), dy.cpu().float().flip(-1), True)
+    tol = (1e-4, 1e-4) if dtype == torch.float32 else (2e-2, 2e-2)
+    close(dxz[:, :48].float(), rdx.flip(-1), *tol)
+    close(dw, rdw, tol[0], tol[1] * max(1.0, rdw.abs().max().item()))
+    close(db, rdb, tol[0], tol[1] * max(1.0, rdb.abs().max().item()))
+    assert float(dxz[:, 48:].abs().max()) == 0.0        # untouched half
