@@ -7,7 +7,7 @@ arithmetic in the HIP library.  PyTorch is used for device memory and the stream
 """
 from __future__ import annotations
 
-import ctypes as C
+import ctypes as ct
 from typing import Optional, Tuple
 
 import torch
@@ -93,7 +93,7 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     x = torch.empty((b, d, num_chunks(l), 2 * A.shape[1]), dtype=torch.float32, device=u.device) if need_x else None
     a.out, a.out_z, a.x = _ptr(out), _ptr(out_z), _ptr(x)
     a.out_bs, a.out_ds = d * l, l
-    N.check(N.lib().cm_selective_scan_fwd(C.byref(a)), "cm_selective_scan_fwd")
+    N.check(N.lib().cm_selective_scan_fwd(ct.byref(a)), "cm_selective_scan_fwd")
     return out, x, out_z
 
 
@@ -135,7 +135,7 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
     if z is not None:
         a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
     a.dA, a.dB, a.dC, a.dD, a.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias)
-    N.check(N.lib().cm_selective_scan_bwd(C.byref(a)), "cm_selective_scan_bwd")
+    N.check(N.lib().cm_selective_scan_bwd(ct.byref(a)), "cm_selective_scan_bwd")
     return du, ddelta, dA, dB, dC, dD, dbias, (dz if z is not None else None), out_z
 
 
@@ -153,7 +153,7 @@ def causal_conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, out: Optio
     a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(w), _ptr(bs), _ptr(y)
     a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
     a.stream = _stream()
-    N.check(N.lib().cm_causal_conv1d_fwd(C.byref(a)), "cm_causal_conv1d_fwd")
+    N.check(N.lib().cm_causal_conv1d_fwd(ct.byref(a)), "cm_causal_conv1d_fwd")
     return y
 
 
@@ -178,5 +178,5 @@ def causal_conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx: Optiona
     a.dy, a.dx, a.dweight, a.dbias = _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db)
     a.dy_bs, a.dy_ds, a.dx_bs, a.dx_ds = dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1)
     a.stream = _stream()
-    N.check(N.lib().cm_causal_conv1d_bwd(C.byref(a)), "cm_causal_conv1d_bwd")
+    N.check(N.lib().cm_causal_conv1d_bwd(ct.byref(a)), "cm_causal_conv1d_bwd")
     return dx, dw, db
