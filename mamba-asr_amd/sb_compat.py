@@ -1,0 +1,281 @@
+"""Minimal stand-ins for the speechbrain==1.0.0 classes the ConMamba recipes instantiate
+(reference hparams/CTC/conmamba_large.yaml:187-326, modules/Conmamba.py:112-121,
+modules/TransformerASR.py:726-734).  speechbrain is not part of the reference tree and is not
+installable here, so these restate its documented semantics with the same
+constructor arguments and state_dict key names; if speechbrain is importable the real classes can be
+used instead — nothing below is needed then.  Parity status: "unpinned" (no reference test covers them)."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Swish(nn.Module):
+    """speechbrain.nnet.activations.Swish(beta=1)."""
+
+    def __init__(self, beta: float = 1.0):
+        super().__init__()
+        self.beta = beta
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.beta * x)
+
+
+class LayerNorm(nn.Module):
+    """speechbrain.nnet.normalization.LayerNorm: nn.LayerNorm under ``.norm`` (keys norm.weight/bias)."""
+
+    def __init__(self, input_size=None, input_shape=None, eps=1e-05, elementwise_affine=True):
+        super().__init__()
+        if input_shape is not None:
+            input_size = input_shape[2:]
+        self.eps = eps
+        self.norm = nn.LayerNorm(input_size, eps=eps, elementwise_affine=elementwise_affine)
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+class Linear(nn.Module):
+    """speechbrain.nnet.linear.Linear: nn.Linear under ``.w``."""
+
+    def __init__(self, n_neurons, input_shape=None, input_size=None, bias=True, combine_dims=False):
+        super().__init__()
+        if input_size is None:
+            input_size = input_shape[-1]
+            if len(input_shape) == 4 and combine_dims:
+                input_size = input_shape[2] * input_shape[3]
+        self.combine_dims = combine_dims
+        self.w = nn.Linear(input_size, n_neurons, bias=bias)
+
+    def forward(self, x):
+        if x.ndim == 4 and self.combine_dims:
+            x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+        return self.w(x)
+
+
+class ModuleList(nn.Module):
+    """speechbrain.nnet.containers.ModuleList(*layers): sequential application, keys layers.N.*"""
+
+    def __init__(self, *layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class PositionalwiseFeedForward(nn.Module):
+    """speechbrain.nnet.attention.PositionalwiseFeedForward: Linear -> act -> Dropout -> Linear (keys ffn.0, ffn.3)."""
+
+    def __init__(self, d_ffn, input_shape=None, input_size=None, dropout=0.0, activation=nn.ReLU):
+        super().__init__()
+        if input_size is None:
+            input_size = input_shape[-1]
+        self.ffn = nn.Sequential(nn.Linear(input_size, d_ffn), activation(), nn.Dropout(dropout),
+                                 nn.Linear(d_ffn, input_size))
+
+    def forward(self, x):
+        return self.ffn(x)
+
+
+# -------------------------------------------------------------------------------------------
+# frontend: Fbank, InputNormalization, SpectrogramDrop / Augmenter, ConvolutionFrontEnd
+# -------------------------------------------------------------------------------------------
+def mel_filterbank(n_mels=80, n_fft=512, sample_rate=16000, f_min=0.0, f_max=None) -> torch.Tensor:
+    """Triangular mel filters of speechbrain's Filterbank: (n_fft//2+1, n_mels)."""
+    f_max = sample_rate / 2 if f_max is None else f_max
+    to_mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    mel = torch.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2)
+    hz = 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    band = (hz[1:] - hz[:-1])[:-1]
+    centre = hz[1:-1]
+    freqs = torch.linspace(0, sample_rate // 2, n_fft // 2 + 1)
+    slope = (freqs[None, :] - centre[:, None]) / band[:, None]
+    return torch.clamp(torch.minimum(slope + 1.0, -slope + 1.0), min=0.0).t().contiguous()
+
+
+class Fbank(nn.Module):
+    """speechbrain.lobes.features.Fbank(sample_rate, n_fft, n_mels, win_length[ms], hop_length[ms]=10):
+    STFT (hamming, centre, constant pad) -> power spectrum -> mel -> 10*log10 (amin 1e-10, top_db 80)."""
+
+    def __init__(self, sample_rate=16000, n_fft=400, n_mels=40, win_length=25, hop_length=10, f_min=0, f_max=None,
+                 deltas=False, context=False, requires_grad=False, top_db=80.0, amin=1e-10):
+        super().__init__()
+        assert not deltas and not context, "deltas/context are not used by the ConMamba recipes"
+        self.sample_rate, self.n_fft, self.n_mels = sample_rate, n_fft, n_mels
+        self.win = int(round(sample_rate / 1000.0 * win_length))
+        self.hop = int(round(sample_rate / 1000.0 * hop_length))
+        self.top_db, self.amin = top_db, amin
+        self.register_buffer("window", torch.hamming_window(self.win), persistent=False)
+        self.register_buffer("fbank", mel_filterbank(n_mels, n_fft, sample_rate, f_min, f_max), persistent=False)
+
+    @torch.no_grad()
+    def forward(self, wav):
+        with torch.autocast(device_type=wav.device.type, enabled=False):          # speechbrain forces fp32 here
+            spec = torch.stft(wav.float(), self.n_fft, self.hop, self.win, self.window, center=True,
+                              pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+            power = (spec.real ** 2 + spec.imag ** 2).transpose(1, 2)
+            mel = power @ self.fbank
+            db = 10.0 * torch.log10(torch.clamp(mel, min=self.amin))
+            floor = db.amax(dim=(-2, -1), keepdim=True) - self.top_db
+            return torch.maximum(db, floor)
+
+
+class InputNormalization(nn.Module):
+    """speechbrain.processing.features.InputNormalization(norm_type='global', update_until_epoch):
+    running average (weight 1/(count+1)) of per-utterance mean/std over valid frames."""
+
+    def __init__(self, mean_norm=True, std_norm=True, norm_type="global", avg_factor=None, requires_grad=False,
+                 update_until_epoch=3):
+        super().__init__()
+        assert norm_type == "global"
+        self.mean_norm, self.std_norm, self.avg_factor = mean_norm, std_norm, avg_factor
+        self.update_until_epoch = update_until_epoch
+        self.register_buffer("glob_mean", torch.zeros(1))
+        self.register_buffer("glob_std", torch.ones(1))
+        self.count = 0
+        self.eps = 1e-10
+
+    def forward(self, x, lengths, spk_ids=None, epoch=0):
+        if self.training and epoch < self.update_until_epoch or self.count == 0:
+            n = torch.round(lengths * x.shape[1]).long().clamp(min=1)
+            mask = (torch.arange(x.shape[1], device=x.device)[None, :] < n[:, None]).to(x.dtype)[..., None]
+            cnt = n.to(x.dtype)[:, None]
+            mean = (x * mask).sum(1) / cnt
+            var = (((x - mean[:, None]) * mask) ** 2).sum(1) / (cnt - 1).clamp(min=1)
+            cur_mean, cur_std = mean.mean(0), var.sqrt().clamp(min=self.eps).mean(0)
+            w = 1.0 / (self.count + 1) if self.avg_factor is None else self.avg_factor
+            if self.count == 0:
+                self.glob_mean, self.glob_std = cur_mean.detach(), cur_std.detach()
+            else:
+                self.glob_mean = ((1 - w) * self.glob_mean + w * cur_mean).detach()
+                self.glob_std = ((1 - w) * self.glob_std + w * cur_std).detach()
+            self.count += 1
+        return (x - self.glob_mean) / self.glob_std
+
+
+class SpectrogramDrop(nn.Module):
+    """speechbrain.augment.freq_domain.SpectrogramDrop(dim in {1,2}, replace='mean'): n_masks ~ U{low..high}
+    per batch, mask length ~ U{len_low..len_high-1}, start ~ U{0..max(1, D-len)-1}; masked cells take the
+    tensor's global mean."""
+
+    def __init__(self, drop_length_low=5, drop_length_high=15, drop_count_low=1, drop_count_high=3, replace="zeros",
+                 dim=1):
+        super().__init__()
+        self.lo, self.hi, self.clo, self.chi, self.replace, self.dim = (drop_length_low, drop_length_high,
+                                                                         drop_count_low, drop_count_high, replace, dim)
+
+    def forward(self, spec):
+        b, size = spec.shape[0], spec.shape[self.dim]
+        n_masks = int(torch.randint(self.clo, self.chi + 1, (1,)))
+        length = torch.randint(self.lo, self.hi, (b, n_masks), device=spec.device)
+        start = torch.randint(0, max(1, size - int(length.max())), (b, n_masks), device=spec.device)
+        ar = torch.arange(size, device=spec.device).view(1, 1, -1)
+        mask = ((ar >= start[..., None]) & (ar < (start + length)[..., None])).any(1)       # (b, size)
+        mask = mask[:, :, None] if self.dim == 1 else mask[:, None, :]
+        val = spec.mean() if self.replace == "mean" else 0.0
+        return spec.masked_fill(mask, float(val) if not torch.is_tensor(val) else val.item())
+
+
+class Augmenter(nn.Module):
+    """speechbrain.augment.augmenter.Augmenter with the recipe settings (sequential, prob 1, no concat)."""
+
+    def __init__(self, parallel_augment=False, concat_original=False, min_augmentations=None, max_augmentations=None,
+                 shuffle_augmentations=False, repeat_augment=1, augment_prob=1.0, augmentations=()):
+        super().__init__()
+        assert not parallel_augment and not concat_original and repeat_augment == 1
+        self.augmentations = nn.ModuleList(augmentations)
+        self.augment_prob = augment_prob
+
+    def forward(self, x, lengths):
+        if float(torch.rand(1)) <= self.augment_prob:
+            for aug in self.augmentations:
+                x = aug(x)
+        return x, lengths
+
+    def replicate_labels(self, labels):
+        return labels
+
+
+class _ConvLayer(nn.Module):
+    def __init__(self, cin, cout, freq, kernel, stride, dropout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel, stride=stride)
+        self.norm = LayerNorm(input_size=(freq, cout))
+        self.act = nn.LeakyReLU(0.01)
+        self.drop = nn.Dropout2d(dropout)
+        self.kernel = kernel
+
+    def forward(self, x):                         # x: (b, t, f, c) channels-last like speechbrain
+        p = self.kernel // 2
+        y = F.pad(x.permute(0, 3, 1, 2), (p, p, p, p), mode="reflect")
+        y = self.conv(y).permute(0, 2, 3, 1)
+        return self.drop(self.act(self.norm(y)).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+
+
+class ConvolutionFrontEnd(nn.Module):
+    """speechbrain.lobes.models.convolution.ConvolutionFrontEnd(input_shape=(b,t,f), num_blocks,
+    num_layers_per_block=1, out_channels, kernel_sizes, strides, residuals): per block Conv2d (stride in time
+    and frequency, 'same' reflect padding) -> LayerNorm over (freq, channel) -> LeakyReLU -> Dropout2d."""
+
+    def __init__(self, input_shape, num_blocks=3, num_layers_per_block=5, out_channels=(128, 256, 512),
+                 kernel_sizes=(3, 3, 3), strides=(1, 2, 2), dilations=(1, 1, 1), residuals=(True, True, True),
+                 dropout=0.1, **unused):
+        super().__init__()
+        assert num_layers_per_block == 1 and not any(residuals[:num_blocks])
+        freq, cin = input_shape[-1], 1
+        blocks = []
+        for i in range(num_blocks):
+            freq = (freq + strides[i] - 1) // strides[i]
+            blocks.append(_ConvLayer(cin, out_channels[i], freq, kernel_sizes[i], strides[i], dropout))
+            cin = out_channels[i]
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        x = x[:, :, :, None]
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+def ctc_loss(log_probs, targets, input_lens, target_lens, blank_index, reduction="mean"):
+    """speechbrain.nnet.losses.ctc_loss: relative lengths -> F.ctc_loss(sum, zero_infinity); 'batchmean' = / batch."""
+    t = log_probs.shape[1]
+    il = torch.round(input_lens * t).int()
+    tl = torch.round(target_lens * targets.shape[1]).int()
+    loss = F.ctc_loss(log_probs.transpose(0, 1).float(), targets, il, tl, blank_index, reduction="sum",
+                      zero_infinity=True)
+    if reduction == "batchmean":
+        return loss / targets.shape[0]
+    if reduction == "mean":
+        return loss / tl.sum()
+    return loss
+
+
+class NoamScheduler:
+    """speechbrain.nnet.schedulers.NoamScheduler: lr = lr0 * sqrt(warm) * min(step^-0.5, step * warm^-1.5)."""
+
+    def __init__(self, lr_initial, n_warmup_steps, model_size=None):
+        self.lr_initial, self.n_warmup_steps, self.n_steps = lr_initial, n_warmup_steps, 0
+        self.normalize = n_warmup_steps ** 0.5 if model_size is None else model_size ** -0.5
+        self.current_lr = lr_initial
+
+    def __call__(self, opt):
+        self.n_steps += 1
+        lr = self.lr_initial * self.normalize * min(self.n_steps ** -0.5, self.n_steps * self.n_warmup_steps ** -1.5)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        old, self.current_lr = self.current_lr, lr
+        return old, lr
+
+    def state_dict(self):
+        return {"n_steps": self.n_steps}
+
+    def load_state_dict(self, sd):
+        self.n_steps = sd["n_steps"]
