@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ConMamba-large CTC encoder forward, audio-frames/sec (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+wav (B x 40 s @ 16 kHz) -> Fbank -> global normalisation -> CNN front end -> src Linear -> 18 ConMamba
+layers -> final LayerNorm (reference train_CTC.py:285-298 + TransformerASR.encode), bf16 autocast, eval.
+Each rank processes its own utterance shard (weak scaling, no data-path collective: SURVEY.md §8e).
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the selective scan) measured with HIP
+events on the launching stream; `cpu_baseline` is the CPU oracle (port of the reference path) on a bounded
+sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="conmamba_large_ctc")
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU (SURVEY §8d config 3: 16 x 40 s)")
+    ap.add_argument("--frames", type=int, default=4000, help="10 ms audio frames per utterance (L)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, cfg, frames, batch):
+    """The oracle (CPU port of the reference path, oracle/conmamba_oracle.py) on `batch` utterances of `frames`
+    audio frames (default: the same batch one GPU step processes): full Fbank -> CNN -> encoder forward, fp32,
+    all host threads.  Checker code, timed here
+    only as the reported baseline."""
+    from oracle import conmamba_oracle as O
+    from mamba_asr_amd.asr import synthetic_wavs, samples_for_frames
+    try:
+        O.load_c_oracle()
+        scan = O.selective_scan_c
+        scan_kind = "C scan (oracle/scan_oracle.c, OpenMP)"
+    except OSError:
+        scan = O.selective_scan
+        scan_kind = "torch time loop"
+    p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    wav, lens = synthetic_wavs(batch, samples_for_frames(frames), cfg.seed, "cpu")
+    mean, std = p["normalize.glob_mean"], p["normalize.glob_std"]
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = O.asr_encode(p, wav, lens, cfg.num_encoder_layers, mean, std, scan=scan, n_fft=cfg.n_fft,
+                           win_ms=cfg.win_length)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"value": round(batch * frames / dt, 1), "unit": "audio-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{batch} utterances x {frames} frames ({frames / 100:.0f} s audio each), one full "
+                      f"frontend+encoder forward, fp32, {scan_kind}, {dt:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
+    from mamba_asr_amd import ops
+    from mamba_asr_amd.asr import CONFIGS, ConMambaASR, samples_for_frames, synthetic_wavs
+
+    cfg = CONFIGS[a.config]
+    model = ConMambaASR(cfg).to(dev).eval()
+    wavs, lens = synthetic_wavs(a.batch, samples_for_frames(a.frames), cfg.seed + rank, dev)
+    amp = torch.bfloat16 if a.dtype == "bf16" else None
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp is not None):
+            return model.encode(wavs, lens)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out.float()).all()
+    frames_total = world * a.batch * a.frames * a.steps
+    value = frames_total / elapsed
+
+    # ---- roofline of the dominant kernel: selective-scan forward, HIP events on its launch stream
+    roof = None
+    if rank == 0:
+        ops.LAUNCH_LOG = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        scans = [(e0.elapsed_time(e1), units) for name, e0, e1, units in log if name == "cm_selective_scan_fwd"]
+        if scans:
+            e_inner, n_state, s = cfg.expand * cfg.d_model, cfg.d_state, (2 if amp is not None else 4)
+            avg_ms = sum(t for t, _ in scans) / len(scans)
+            units = scans[0][1]                                      # scan steps (batch * T) per launch
+            alg_bytes = units * (4 * e_inner + 2 * n_state) * s      # (4E+2N)*s per scan step
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "scan_fwd_kernel (cm_selective_scan_fwd)", "avg_launch_us": round(avg_ms * 1e3, 1),
+                    "launches_per_step": len(scans) // 3, "alg_bytes_per_launch": alg_bytes}
+
+    base = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        base = cpu_baseline(model, cfg, a.cpu_frames, a.cpu_batch)
+
+    if rank == 0:
+        # whole-path roofline position (SURVEY §8d canonical bytes per audio frame, bf16)
+        bytes_per_frame = {"conmamba_large_ctc": 168464, "conmamba_small_ctc": 74568,
+                           "conmambamamba_large_s2s": 226564}.get(a.config)
+        line = {
+            "metric": "encoder audio-frames/sec (ConMamba-large, L=4000)", "value": round(value, 1),
+            "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: encoder forward, {a.batch} utterances x {a.frames} frames "
+                                   f"({a.frames // 4} scan steps) per GPU, random-init weights",
+                       "global_batch": world * a.batch, "frames_per_utterance": a.frames,
+                       "parallelism": f"utterance shards x{world} (no collective in forward)"},
+            "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
+            "roofline": roof, "cpu_baseline": base,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

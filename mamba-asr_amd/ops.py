@@ -17,6 +17,24 @@ from . import _native as N
 _DT = {torch.float32: N.CM_F32, torch.bfloat16: N.CM_BF16, torch.float16: N.CM_F16}
 
 
+# When set to a list, every native launch is bracketed by HIP events recorded on the stream the kernel
+# is launched on; entries are (kernel_name, start_event, end_event, units).  Used by bench.py's roofline leg.
+LAUNCH_LOG: Optional[list] = None
+
+
+def _launch(name: str, fn, args, units: int = 0):
+    log = LAUNCH_LOG
+    if log is None:
+        N.check(fn(ct.byref(args)), name)
+        return
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    N.check(fn(ct.byref(args)), name)
+    e1.record(st)
+    log.append((name, e0, e1, units))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -93,7 +111,7 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     x = torch.empty((b, d, num_chunks(l), 2 * A.shape[1]), dtype=torch.float32, device=u.device) if need_x else None
     a.out, a.out_z, a.x = _ptr(out), _ptr(out_z), _ptr(x)
     a.out_bs, a.out_ds = d * l, l
-    N.check(N.lib().cm_selective_scan_fwd(ct.byref(a)), "cm_selective_scan_fwd")
+    _launch("cm_selective_scan_fwd", N.lib().cm_selective_scan_fwd, a, units=b * l)
     return out, x, out_z
 
 
@@ -135,7 +153,7 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
     if z is not None:
         a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
     a.dA, a.dB, a.dC, a.dD, a.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias)
-    N.check(N.lib().cm_selective_scan_bwd(ct.byref(a)), "cm_selective_scan_bwd")
+    _launch("cm_selective_scan_bwd", N.lib().cm_selective_scan_bwd, a, units=b * l)
     return du, ddelta, dA, dB, dC, dD, dbias, (dz if z is not None else None), out_z
 
 
@@ -153,7 +171,7 @@ def causal_conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, out: Optio
     a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(w), _ptr(bs), _ptr(y)
     a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
     a.stream = _stream()
-    N.check(N.lib().cm_causal_conv1d_fwd(ct.byref(a)), "cm_causal_conv1d_fwd")
+    _launch("cm_causal_conv1d_fwd", N.lib().cm_causal_conv1d_fwd, a, units=b * l)
     return y
 
 
@@ -178,5 +196,5 @@ def causal_conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx: Optiona
     a.dy, a.dx, a.dweight, a.dbias = _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db)
     a.dy_bs, a.dy_ds, a.dx_bs, a.dx_ds = dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1)
     a.stream = _stream()
-    N.check(N.lib().cm_causal_conv1d_bwd(ct.byref(a)), "cm_causal_conv1d_bwd")
+    _launch("cm_causal_conv1d_bwd", N.lib().cm_causal_conv1d_bwd, a, units=b * l)
     return dx, dw, db

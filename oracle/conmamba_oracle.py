@@ -433,23 +433,34 @@ def global_norm_stats(feats: torch.Tensor, lens: torch.Tensor):
 
 
 def cnn_frontend(p, feats, prefix=""):
-    """ConvolutionFrontEnd(2 blocks, 1 layer each, channels (64, 32), k=3, stride 2, 'same' pad,
-    LayerNorm over (freq, ch), LeakyReLU(0.01)) — conmamba_large.yaml:187-194; eval mode.
-    feats (b, t, 80) -> (b, ceil(t/4), 20, 32)."""
+    """ConvolutionFrontEnd(2 blocks, 1 layer each, channels (64, 32), k=3, stride 2 in time and frequency,
+    'same' reflect padding, LayerNorm over (freq, ch), LeakyReLU(0.01)) — conmamba_large.yaml:187-194; eval
+    mode.  feats (b, t, 80) -> (b, ceil(t/4), 20, 32).  Parameter names: blocks.{i}.conv.{weight,bias},
+    blocks.{i}.norm.norm.{weight,bias} (the build's naming; speechbrain's own key names are unpinned)."""
     x = feats[:, :, :, None]                                                    # b t f 1 (channels-last)
     for blk in range(2):
-        w = p[f"{prefix}convblock_{blk}.convlayer_0.conv.weight"].to(x.dtype)   # (co, ci, 3, 3)
-        bb = p[f"{prefix}convblock_{blk}.convlayer_0.conv.bias"].to(x.dtype)
-        xin = x.permute(0, 3, 1, 2)                                             # b c t f
-        # speechbrain "same" padding with stride 2: reflect-free symmetric pad k//2 computed from L_in
-        xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
-        y = F.conv2d(xin, w, bb, stride=2)
-        y = y.permute(0, 2, 3, 1)                                               # b t f c
-        lw = p[f"{prefix}convblock_{blk}.convlayer_0.norm.norm.weight"].to(x.dtype)
-        lb = p[f"{prefix}convblock_{blk}.convlayer_0.norm.norm.bias"].to(x.dtype)
-        y = F.layer_norm(y, tuple(y.shape[-2:]), lw, lb, 1e-5)
-        x = F.leaky_relu(y, 0.01)
+        w = p[f"{prefix}blocks.{blk}.conv.weight"].to(x.dtype)                  # (co, ci, 3, 3)
+        bb = p[f"{prefix}blocks.{blk}.conv.bias"].to(x.dtype)
+        xin = F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")        # b c t f, pad k//2
+        y = F.conv2d(xin, w, bb, stride=2).permute(0, 2, 3, 1)                  # b t f c
+        lw = p[f"{prefix}blocks.{blk}.norm.norm.weight"].to(x.dtype)
+        lb = p[f"{prefix}blocks.{blk}.norm.norm.bias"].to(x.dtype)
+        x = F.leaky_relu(F.layer_norm(y, tuple(y.shape[-2:]), lw, lb, 1e-5), 0.01)
     return x
+
+
+def asr_encode(p, wav, wav_lens, num_layers, norm_mean, norm_std, scan=selective_scan, n_fft=512, win_ms=25):
+    """Full CTC encoder forward in eval mode, train_CTC.py:285-298: Fbank -> global normalisation -> CNN front
+    end -> reshape + Linear (TransformerASR.py:760-773) -> ConmambaEncoder.  ``p`` holds 'CNN.*' and
+    'Transformer.*' parameters under the reference state_dict names."""
+    feats = fbank(wav, n_fft=n_fft, win_ms=win_ms)
+    feats = (feats - norm_mean) / norm_std
+    src = cnn_frontend(p, feats, "CNN.")
+    b, t = src.shape[:2]
+    src = src.reshape(b, t, -1)
+    src = F.linear(src, p["Transformer.custom_src_module.layers.0.w.weight"],
+                   p["Transformer.custom_src_module.layers.0.w.bias"])
+    return encoder(p, src, num_layers, "Transformer.encoder.", scan)
 
 
 def ctc_loss_batchmean(log_probs, targets, in_lens_rel, tgt_lens_rel, blank=0):
