@@ -60,7 +60,7 @@ def cpu_baseline(model, cfg, frames, batch):
     p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     wav, lens = synthetic_wavs(batch, samples_for_frames(frames), cfg.seed, "cpu")
     mean, std = p["normalize.glob_mean"], p["normalize.glob_std"]
-    torch.set_num_threads(os.cpu_count() or 1)
+    O.set_threads(O.host_threads(16))
     t0 = time.perf_counter()
     with torch.no_grad():
         out = O.asr_encode(p, wav, lens, cfg.num_encoder_layers, mean, std, scan=scan, n_fft=cfg.n_fft,

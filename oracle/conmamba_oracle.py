@@ -63,8 +63,27 @@ def load_c_oracle():
         lib.oracle_causal_conv1d_fwd_f32.argtypes = [
             fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
         lib.oracle_causal_conv1d_fwd_f32.restype = None
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_set_threads.restype = None
         _C_LIB = lib
     return _C_LIB
+
+
+def host_threads(cap: int = 16) -> int:
+    """Threads the CPU baseline may use: the process's CPU affinity, capped (a one-GPU box share is 16 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
+def set_threads(n: int) -> None:
+    torch.set_num_threads(n)
+    try:
+        load_c_oracle().oracle_set_threads(n)
+    except OSError:
+        pass
 
 
 def _fptr(t: Optional[torch.Tensor]):
