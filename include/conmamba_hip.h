@@ -157,6 +157,118 @@ typedef struct cm_conv_args {
 int cm_causal_conv1d_fwd(const cm_conv_args *args);
 int cm_causal_conv1d_bwd(const cm_conv_args *args);
 
+
+/* ---------------------------------------------------------------------------------------
+ * Channels-last selective scan forward — the MI355X-native layout of the fused BiMamba path.
+ * Same math as cm_selective_scan_fwd, but activations are (batch, seqlen, dim) with the channel
+ * axis contiguous (what the in_proj GEMM writes: reference bimamba.py:192-196 produces the same
+ * numbers transposed), B/C are fp32 (dstate, batch, seqlen) with time contiguous, and up to two
+ * independent directions (the two halves of BiMamba v2, reference bimamba.py:223-248) run in ONE
+ * launch: direction d uses its own u/delta/A/B/C/D/delta_bias/out and walks time forward
+ * (reverse[d] == 0) or backward.  z is shared.  Row (time) and batch strides are in elements, so
+ * z / out may be column slices of wider buffers ([x|z], [y_fwd|y_bwd]).
+ * B/C rows must be readable up to the next multiple of 16 steps past seqlen (pad the allocation).
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_scan_cl_dir {
+    const void  *u;          /* (batch, seqlen, dim)  conv+SiLU output                      */
+    const void  *delta;      /* (batch, seqlen, dim)  pre-bias, pre-softplus                */
+    const float *A;          /* (dim, dstate)                                               */
+    const float *B;          /* (dstate, batch, seqlen) fp32                                */
+    const float *C;
+    const float *D;          /* (dim) or NULL                                               */
+    const float *delta_bias; /* (dim) or NULL                                               */
+    void        *out;        /* (batch, seqlen, dim)  gated output                          */
+    int64_t u_bs, u_ts, delta_bs, delta_ts, out_bs, out_ts;
+    int64_t bc_ns, bc_bs;    /* state / batch strides of B and C                            */
+    int32_t reverse_time;
+    int32_t pad_;
+} cm_scan_cl_dir;
+
+typedef struct cm_scan_cl_args {
+    int32_t batch, seqlen, dim, dstate;
+    int32_t io_dtype;        /* CM_BF16 or CM_F32: u, delta, z, out                         */
+    int32_t delta_softplus;
+    int32_t ndir;            /* 1 or 2                                                      */
+    int32_t pad_;
+    const void *z;           /* (batch, seqlen, dim) or NULL                                */
+    int64_t z_bs, z_ts;
+    cm_scan_cl_dir dir[2];
+    void *stream;
+} cm_scan_cl_args;
+
+int cm_scan_cl_fwd(const cm_scan_cl_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * Channels-last causal conv, both BiMamba directions in one pass over x.
+ *   y_fwd[b,t,c] = silu(bias_f[c] + sum_k w_f[c,k] x[b,t-(W-1)+k,c])      (causal,  bimamba.py:223-235)
+ *   y_bwd[b,t,c] = silu(bias_b[c] + sum_k w_b[c,k] x[b,t+(W-1)-k,c])      (the reference's flipped branch,
+ *                                                                           bimamba.py:236-248, un-flipped)
+ * x, y_fwd, y_bwd: (batch, seqlen, dim), channel axis contiguous, strides in elements; width 4.
+ * y_bwd / weight_b / bias_b may be NULL for a single (causal) direction.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_conv_cl_args {
+    int32_t batch, seqlen, dim, width;
+    int32_t io_dtype;            /* CM_BF16 or CM_F32 */
+    int32_t silu;
+    const void  *x;
+    const float *weight_f, *bias_f, *weight_b, *bias_b;   /* (dim, width) / (dim); bias may be NULL */
+    void *y_fwd, *y_bwd;
+    int64_t x_bs, x_ts, yf_bs, yf_ts, yb_bs, yb_ts;
+    void *stream;
+} cm_conv_cl_args;
+
+int cm_conv_cl_fwd(const cm_conv_cl_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * Residual add + LayerNorm(s) over the last axis (rows x dim), fused:
+ *   r   = x + alpha * y                       (y optional; x fp32 residual stream)
+ *   if norm1: r1 = LN(r; g1, b1, eps1) else r1 = r
+ *   if x_out: x_out = r1 (fp32)               -- new residual stream (may alias x)
+ *   if norm2: out = LN(r1; g2, b2, eps2) else out = r1;  written in out_dtype if out != NULL
+ * Covers the four residual/normalisation seams of ConmambaEncoderLayer.forward
+ * (reference modules/Conmamba.py:638-649) and the encoder's final norm (:725).
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_add_ln_args {
+    int64_t rows;
+    int32_t dim;
+    int32_t y_dtype;             /* dtype of y (CM_BF16 / CM_F32)        */
+    int32_t out_dtype;           /* dtype of out                          */
+    int32_t pad_;
+    const float *x;              /* (rows, dim) fp32                      */
+    const void  *y;              /* (rows, dim) or NULL                   */
+    float alpha;
+    float eps1, eps2;
+    int32_t pad2_;
+    const float *g1, *b1;        /* first LN (applied to the residual) or NULL  */
+    const float *g2, *b2;        /* second LN (produces `out`) or NULL          */
+    float *x_out;                /* (rows, dim) fp32 or NULL                    */
+    void  *out;                  /* (rows, dim) out_dtype or NULL               */
+    void  *stream;
+} cm_add_ln_args;
+
+int cm_add_layernorm(const cm_add_ln_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * ConvolutionModule core, channels-last (reference modules/Conmamba.py:441-449 between the two
+ * GEMMs): GLU over the channel axis -> depthwise conv over time (kernel K odd, 'same' zero padding)
+ * + bias -> LayerNorm(dim) -> GELU.   in: (batch, seqlen, 2*dim)  out: (batch, seqlen, dim)
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_glu_dwconv_args {
+    int32_t batch, seqlen, dim, ksize;
+    int32_t io_dtype;
+    int32_t pad_;
+    const void  *in;             /* (batch, seqlen, 2*dim), contiguous               */
+    const float *weight;         /* (dim, ksize) depthwise taps                       */
+    const float *bias;           /* (dim) or NULL                                      */
+    const float *ln_g, *ln_b;    /* (dim)                                              */
+    float eps;
+    int32_t pad2_;
+    void *out;                   /* (batch, seqlen, dim), contiguous                   */
+    void *stream;
+} cm_glu_dwconv_args;
+
+int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
+
 #ifdef __cplusplus
 }
 #endif

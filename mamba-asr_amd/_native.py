@@ -53,6 +53,49 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ScanClDir(C.Structure):
+    _fields_ = [
+        ("u", vp), ("delta", vp), ("A", fp), ("B", fp), ("C", fp), ("D", fp), ("delta_bias", fp), ("out", vp),
+        ("u_bs", i64), ("u_ts", i64), ("delta_bs", i64), ("delta_ts", i64), ("out_bs", i64), ("out_ts", i64),
+        ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("pad_", i32),
+    ]
+
+
+class ScanClArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32),
+        ("io_dtype", i32), ("delta_softplus", i32), ("ndir", i32), ("pad_", i32),
+        ("z", vp), ("z_bs", i64), ("z_ts", i64),
+        ("dir", ScanClDir * 2),
+        ("stream", vp),
+    ]
+
+
+class ConvClArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("width", i32), ("io_dtype", i32), ("silu", i32),
+        ("x", vp), ("weight_f", fp), ("bias_f", fp), ("weight_b", fp), ("bias_b", fp), ("y_fwd", vp), ("y_bwd", vp),
+        ("x_bs", i64), ("x_ts", i64), ("yf_bs", i64), ("yf_ts", i64), ("yb_bs", i64), ("yb_ts", i64),
+        ("stream", vp),
+    ]
+
+
+class AddLnArgs(C.Structure):
+    _fields_ = [
+        ("rows", i64), ("dim", i32), ("y_dtype", i32), ("out_dtype", i32), ("pad_", i32),
+        ("x", fp), ("y", vp), ("alpha", C.c_float), ("eps1", C.c_float), ("eps2", C.c_float), ("pad2_", i32),
+        ("g1", fp), ("b1", fp), ("g2", fp), ("b2", fp), ("x_out", fp), ("out", vp), ("stream", vp),
+    ]
+
+
+class GluDwconvArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("pad_", i32),
+        ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
+        ("out", vp), ("stream", vp),
+    ]
+
+
 # every symbol include/conmamba_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("cm_abi_version", C.c_int, []),
@@ -63,6 +106,10 @@ SYMBOLS = [
     ("cm_selective_scan_bwd", C.c_int, [C.POINTER(ScanBwdArgs)]),
     ("cm_causal_conv1d_fwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
+    ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
+    ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
+    ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
+    ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
 ]
 
 _lib = None

@@ -1,0 +1,336 @@
+// elementwise_cl.hip — channels-last streaming kernels of the fused ConMamba layer (gfx950):
+//   cm_conv_cl_fwd         depthwise causal conv + SiLU for both BiMamba directions in one pass
+//   cm_add_layernorm       residual add + one or two LayerNorms
+//   cm_glu_dwconv_ln_gelu  GLU -> depthwise conv k (31) -> LayerNorm -> GELU of the convolution module
+// All are HBM-bound: 16-byte vectors along the contiguous channel axis, every input read once.
+#include "cm_common.h"
+
+namespace {
+
+template <typename IO> struct vec8 {                  // 16-byte vector of IO elements <-> floats
+    static constexpr int N = cm_elem<IO>::kVec;
+    static __device__ __forceinline__ void load(const IO *p, float (&f)[N]) {
+        alignas(16) IO tmp[N];
+        *reinterpret_cast<uint4 *>(tmp) = *reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+        for (int j = 0; j < N; ++j) f[j] = cm_elem<IO>::load(&tmp[j]);
+    }
+    static __device__ __forceinline__ void store(IO *p, const float (&f)[N]) {
+        alignas(16) IO tmp[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) cm_elem<IO>::store(&tmp[j], f[j]);
+        *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(tmp);
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// ------------------------------------------------------------------------------------------------
+// conv, both directions.  One thread owns one 16-byte channel vector and walks a run of TC steps with a
+// rolling window of W rows: the newest W rows x[s-W+1..s] give y_fwd[s] and y_bwd[s-W+1].
+// ------------------------------------------------------------------------------------------------
+template <typename IO, int W>
+__global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, int vpr, int tc) {
+    constexpr int N = cm_elem<IO>::kVec;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;          // flat (chunk, vector) index
+    const int nchunk = (p.seqlen + tc - 1) / tc;
+    const int vec = v % vpr, chunk = (v / vpr) % nchunk, b = v / (vpr * nchunk);
+    if (b >= p.batch) return;
+    const int c0 = vec * N;
+    const bool two = p.y_bwd != nullptr;
+    float wf[N][W], wb[N][W], bf[N], bb[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            wf[j][k] = p.weight_f[(c0 + j) * W + k];
+            wb[j][k] = two ? p.weight_b[(c0 + j) * W + k] : 0.f;
+        }
+        bf[j] = p.bias_f ? p.bias_f[c0 + j] : 0.f;
+        bb[j] = (two && p.bias_b) ? p.bias_b[c0 + j] : 0.f;
+    }
+    const IO *x = reinterpret_cast<const IO *>(p.x) + (int64_t)b * p.x_bs + c0;
+    IO *yf = reinterpret_cast<IO *>(p.y_fwd) + (int64_t)b * p.yf_bs + c0;
+    IO *yb = two ? reinterpret_cast<IO *>(p.y_bwd) + (int64_t)b * p.yb_bs + c0 : nullptr;
+    const int t0 = chunk * tc, t1 = min(t0 + tc, p.seqlen);
+    float win[W][N];                                              // win[k] = x[s-(W-1)+k]
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j) win[k][j] = 0.f;
+    for (int s = t0 - (W - 1); s < t1 + (W - 1); ++s) {
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k)
+#pragma unroll
+            for (int j = 0; j < N; ++j) win[k][j] = win[k + 1][j];
+        if (s >= 0 && s < p.seqlen) vec8<IO>::load(x + (int64_t)s * p.x_ts, win[W - 1]);
+        else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) win[W - 1][j] = 0.f;
+        }
+        if (s >= t0 && s < t1) {                                  // causal output at s
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float acc = bf[j];
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc = fmaf(wf[j][k], win[k][j], acc);
+                o[j] = p.silu ? acc * cm_sigmoid(acc) : acc;
+            }
+            vec8<IO>::store(yf + (int64_t)s * p.yf_ts, o);
+        }
+        const int sb = s - (W - 1);                               // anti-causal output at s-(W-1)
+        if (two && sb >= t0 && sb < t1) {
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float acc = bb[j];
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc = fmaf(wb[j][k], win[W - 1 - k][j], acc);   // tap k <-> x[t+(W-1)-k]
+                o[j] = p.silu ? acc * cm_sigmoid(acc) : acc;
+            }
+            vec8<IO>::store(yb + (int64_t)sb * p.yb_ts, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// add + LayerNorm(s): one wave per row, float4 per lane per 256 columns.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename YT, typename OT, int NV>          // NV = float4 groups per lane (dim <= NV*256)
+__global__ __launch_bounds__(256) void add_ln_kernel(const cm_add_ln_args p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int D = p.dim;
+    float r[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 xv = *reinterpret_cast<const float4 *>(p.x + row * D + c);
+            r[i][0] = xv.x; r[i][1] = xv.y; r[i][2] = xv.z; r[i][3] = xv.w;
+            if (p.y) {
+                const YT *yp = reinterpret_cast<const YT *>(p.y) + row * D + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i][j] = fmaf(p.alpha, cm_elem<YT>::load(yp + j), r[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[i][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += r[i][j];
+    }
+    auto layer_norm = [&](const float *g, const float *bta, float eps) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += r[i][j];
+        const float mean = wave_sum(sum) / D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dlt = (c < D) ? r[i][j] - mean : 0.f;
+                sq += dlt * dlt;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / D + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i][j] = (r[i][j] - mean) * rstd * g[c + j] + bta[c + j];
+            }
+        }
+    };
+    (void)s;
+    if (p.g1) layer_norm(p.g1, p.b1, p.eps1);
+    if (p.x_out) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) *reinterpret_cast<float4 *>(p.x_out + row * D + c) = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
+        }
+    }
+    if (p.out) {
+        if (p.g2) layer_norm(p.g2, p.b2, p.eps2);
+        OT *op = reinterpret_cast<OT *>(p.out) + row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cm_elem<OT>::store(op + c + j, r[i][j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLU -> depthwise conv (K taps, same padding) -> LayerNorm -> GELU.
+// Workgroup = one batch row x TT output steps; thread = channel.  Phase 1: GLU of the TT+K-1 input rows
+// into LDS (each input element read once from HBM).  Phase 2: thread c convolves its channel along time
+// from LDS (conflict-free: consecutive threads, consecutive addresses) and writes the result back to LDS.
+// Phase 3: one wave per output row does LayerNorm + GELU and the coalesced store.
+// ------------------------------------------------------------------------------------------------
+template <typename IO, int K, int TT>
+__global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_args p) {
+    constexpr int tt = TT;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = p.dim, T = p.seqlen;
+    const int b = blockIdx.y, t0 = blockIdx.x * tt;
+    const int nin = tt + K - 1;                                   // input rows t0-K/2 .. t0+tt-1+K/2
+    float *g = sm;                                                // [nin][D]
+    float *co = sm + (size_t)nin * D;                             // [tt][D]
+    const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * 2 * D;
+    // phase 1: GLU rows -> LDS  (a = in[:, :D], gate = in[:, D:])
+    for (int idx = threadIdx.x; idx < nin * (D / 2); idx += blockDim.x) {
+        const int r = idx / (D / 2), c = (idx % (D / 2)) * 2;
+        const int t = t0 - K / 2 + r;
+        float v0 = 0.f, v1 = 0.f;
+        if (t >= 0 && t < T) {
+            const IO *row = in + (int64_t)t * 2 * D;
+            const float a0 = cm_elem<IO>::load(row + c), a1 = cm_elem<IO>::load(row + c + 1);
+            const float g0 = cm_elem<IO>::load(row + D + c), g1 = cm_elem<IO>::load(row + D + c + 1);
+            v0 = a0 * cm_sigmoid(g0);
+            v1 = a1 * cm_sigmoid(g1);
+        }
+        g[r * D + c] = v0;
+        g[r * D + c + 1] = v1;
+    }
+    __syncthreads();
+    // phase 2: depthwise conv along time
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = p.weight[c * K + k];
+        const float bias = p.bias ? p.bias[c] : 0.f;
+        float col[TT + K - 1];                                     // this channel's GLU outputs over the tile (+halo)
+#pragma unroll
+        for (int r = 0; r < TT + K - 1; ++r) col[r] = g[r * D + c];
+#pragma unroll
+        for (int r = 0; r < TT; ++r) {
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc = fmaf(w[k], col[r + k], acc);
+            co[r * D + c] = acc;
+        }
+    }
+    __syncthreads();
+    // phase 3: LayerNorm + GELU per row, one wave per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    IO *out = reinterpret_cast<IO *>(p.out) + (int64_t)b * T * D;
+    for (int r = wave; r < tt; r += 4) {
+        const int t = t0 + r;
+        if (t >= T) break;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += co[r * D + c];
+        const float mean = wave_sum(s) / D;
+        float sq = 0.f;
+        for (int c = lane; c < D; c += 64) { const float dl = co[r * D + c] - mean; sq += dl * dl; }
+        const float rstd = rsqrtf(wave_sum(sq) / D + p.eps);
+        for (int c = lane; c < D; c += 64) {
+            const float v = (co[r * D + c] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
+            cm_elem<IO>::store(out + (int64_t)t * D + c, gelu_erf(v));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "conv_cl_fwd: args is NULL");
+    const cm_conv_cl_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.seqlen > 0 && a.dim > 0, CM_EINVAL, "conv_cl_fwd: bad sizes");
+    CM_REQUIRE(a.width == 4, CM_EUNSUPPORTED, "conv_cl_fwd: width %d unsupported (4 only)", a.width);
+    CM_REQUIRE(a.x && a.weight_f && a.y_fwd, CM_EINVAL, "conv_cl_fwd: x/weight_f/y_fwd must be non-NULL");
+    CM_REQUIRE(!a.y_bwd || a.weight_b, CM_EINVAL, "conv_cl_fwd: y_bwd given without weight_b");
+    const int n = a.io_dtype == CM_F32 ? 4 : 8;
+    auto ok = [&](const void *ptr, int64_t bs, int64_t ts) { return !ptr || (cm_aligned(ptr, 16) && bs % n == 0 && ts % n == 0); };
+    CM_REQUIRE(a.dim % n == 0 && ok(a.x, a.x_bs, a.x_ts) && ok(a.y_fwd, a.yf_bs, a.yf_ts) && ok(a.y_bwd, a.yb_bs, a.yb_ts),
+               CM_EALIGN, "conv_cl_fwd: dim and strides must be multiples of %d elements, pointers 16-byte aligned", n);
+    const int vpr = a.dim / n;
+    const int tc = 32;
+    const int64_t threads = (int64_t)a.batch * ((a.seqlen + tc - 1) / tc) * vpr;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((conv_cl_kernel<cm_bf16, 4>), grid, dim3(256), 0, st, a, vpr, tc);
+    else if (a.io_dtype == CM_F32) hipLaunchKernelGGL((conv_cl_kernel<float, 4>), grid, dim3(256), 0, st, a, vpr, tc);
+    else { cm_set_error("conv_cl_fwd: unsupported dtype %d", a.io_dtype); return CM_EUNSUPPORTED; }
+    return cm_launch_status("cm_conv_cl_fwd");
+}
+
+extern "C" int cm_add_layernorm(const cm_add_ln_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "add_layernorm: args is NULL");
+    const cm_add_ln_args &a = *args;
+    CM_REQUIRE(a.rows > 0 && a.dim > 0 && a.x, CM_EINVAL, "add_layernorm: bad sizes / x is NULL");
+    CM_REQUIRE(a.dim % 4 == 0 && a.dim <= 1024, CM_EUNSUPPORTED, "add_layernorm: dim %d unsupported (multiple of 4, <= 1024)", a.dim);
+    CM_REQUIRE((!a.g1 || a.b1) && (!a.g2 || a.b2), CM_EINVAL, "add_layernorm: LayerNorm weight without bias");
+    dim3 grid((unsigned)((a.rows + 3) / 4));
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    const int nv = (a.dim + 255) / 256;
+    const int key = (a.y_dtype == CM_BF16 ? 0 : 1) * 2 + (a.out_dtype == CM_BF16 ? 0 : 1);
+#define CM_LN(YT, OT)                                                                                   \
+    switch (nv) {                                                                                       \
+        case 1: hipLaunchKernelGGL((add_ln_kernel<YT, OT, 1>), grid, dim3(256), 0, st, a); break;       \
+        case 2: hipLaunchKernelGGL((add_ln_kernel<YT, OT, 2>), grid, dim3(256), 0, st, a); break;       \
+        default: hipLaunchKernelGGL((add_ln_kernel<YT, OT, 4>), grid, dim3(256), 0, st, a); break;      \
+    }
+    switch (key) {
+        case 0: CM_LN(cm_bf16, cm_bf16) break;
+        case 1: CM_LN(cm_bf16, float) break;
+        case 2: CM_LN(float, cm_bf16) break;
+        default: CM_LN(float, float) break;
+    }
+#undef CM_LN
+    return cm_launch_status("cm_add_layernorm");
+}
+
+extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "glu_dwconv: args is NULL");
+    const cm_glu_dwconv_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.seqlen > 0 && a.dim > 0 && a.in && a.out && a.weight && a.ln_g && a.ln_b, CM_EINVAL,
+               "glu_dwconv: bad sizes or NULL tensor");
+    CM_REQUIRE(a.ksize == 31, CM_EUNSUPPORTED, "glu_dwconv: kernel size %d unsupported (31 only)", a.ksize);
+    CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
+    // time tile: LDS holds (tt + K - 1 + tt) rows of dim floats; keep it under 64 KB so 2 workgroups share a CU
+    int tt = 16;
+    while (tt > 4 && (size_t)(2 * tt + 30) * a.dim * 4 > 64 * 1024) tt /= 2;
+    const size_t smem = (size_t)(2 * tt + 30) * a.dim * 4;
+    dim3 grid((a.seqlen + tt - 1) / tt, a.batch);
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    auto go = [&](auto kern) -> int {
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { cm_set_error("glu_dwconv: LDS attribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+        return cm_launch_status("cm_glu_dwconv_ln_gelu");
+    };
+    if (a.io_dtype == CM_BF16) {
+        if (tt == 16) return go(glu_dwconv_kernel<cm_bf16, 31, 16>);
+        if (tt == 8) return go(glu_dwconv_kernel<cm_bf16, 31, 8>);
+        return go(glu_dwconv_kernel<cm_bf16, 31, 4>);
+    }
+    if (a.io_dtype == CM_F32) {
+        if (tt == 16) return go(glu_dwconv_kernel<float, 31, 16>);
+        if (tt == 8) return go(glu_dwconv_kernel<float, 31, 8>);
+        return go(glu_dwconv_kernel<float, 31, 4>);
+    }
+    cm_set_error("glu_dwconv: unsupported dtype %d", a.io_dtype);
+    return CM_EUNSUPPORTED;
+}

@@ -15,13 +15,19 @@ extern "C" int cm_scan_set_split(int lanes_per_channel) {
     return g_split_override.exchange(lanes_per_channel);
 }
 
-int cm_scan_pick_split(int batch, int dim, int dstate) {
+// 0 = no override (automatic), else the requested lanes per channel
+int cm_scan_split_override() {
     int env = g_split_override.load();
     if (env < 0) {
         const char *s = getenv("CM_SCAN_SPLIT");
         env = s ? atoi(s) : 0;
         g_split_override.store(env);
     }
+    return (env >= 1 && (env & (env - 1)) == 0) ? env : 0;
+}
+
+int cm_scan_pick_split(int batch, int dim, int dstate) {
+    const int env = cm_scan_split_override();
     const int smax = dstate < 16 ? dstate : 16;
     if (env >= 1 && (env & (env - 1)) == 0) return env <= smax ? env : smax;
     int S = 1;

@@ -1,0 +1,161 @@
+"""Fused MI355X forward of the ConMamba encoder (inference / no-grad path).
+
+Same numbers as ConmambaEncoder.forward (reference modules/Conmamba.py:631-650, :716-727 and
+modules/mamba/bimamba.py:192-253), but laid out for the hardware instead of mirroring the reference's op
+sequence:
+  * activations stay channels-last (rows = batch*time, channel axis contiguous) end to end: no transposes,
+    no .flip() copies, no .contiguous() round trips;
+  * the residual stream is fp32 (as under the reference's bf16 autocast, where LayerNorm outputs fp32), every
+    GEMM operand is the compute dtype, and each residual-add + LayerNorm seam is ONE kernel (cm_add_layernorm);
+  * both BiMamba directions share one conv launch (cm_conv_cl_fwd) and one scan launch (cm_scan_cl_fwd); the
+    0.5*(fwd+bwd) average is folded into out_proj by K-concatenation: [y_f | y_b] @ (0.5*[W_out | W_out])^T;
+  * GLU -> depthwise conv k=31 -> LayerNorm -> GELU of the convolution module is one kernel.
+GEMMs go to the vendor library through torch (hipBLASLt/rocBLAS): plain library GEMMs, not the product.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _LayerCache:
+    """Per-layer GEMM weights in the compute dtype and small fp32 vectors, rebuilt when parameters change."""
+
+    def __init__(self, layer, dtype):
+        self.dtype = dtype
+        self.version = self._ver(layer)
+        c = lambda t: t.detach().to(dtype).contiguous()
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        ffn = lambda m: dict(ln=(f(m[0].weight), f(m[0].bias), m[0].eps), w1=c(m[1].ffn[0].weight), b1=c(m[1].ffn[0].bias),
+                             w2=c(m[1].ffn[3].weight), b2=c(m[1].ffn[3].bias))
+        self.ffn1, self.ffn2 = ffn(layer.ffn_module1), ffn(layer.ffn_module2)
+        self.norm1 = (f(layer.norm1.norm.weight), f(layer.norm1.norm.bias), layer.norm1.norm.eps)
+        self.norm2 = (f(layer.norm2.norm.weight), f(layer.norm2.norm.bias), layer.norm2.norm.eps)
+        m = layer.mamba
+        self.d_inner, self.dt_rank, self.d_state = m.d_inner, m.dt_rank, m.d_state
+        self.in_proj = c(m.in_proj.weight)
+        self.in_bias = None if m.in_proj.bias is None else c(m.in_proj.bias)
+        half = 0.5 if m.if_devide_out else 1.0
+        self.out_cat = c(torch.cat([m.out_proj.weight, m.out_proj.weight], dim=1) * half)      # (D, 2E)
+        self.out_bias = None if m.out_proj.bias is None else c(m.out_proj.bias)
+        self.gamma = None if m.init_layer_scale is None else f(m.gamma)
+        self.dirs = []
+        for sfx in ("", "_b"):
+            conv, xp, dtp = getattr(m, "conv1d" + sfx), getattr(m, "x_proj" + sfx), getattr(m, "dt_proj" + sfx)
+            A_log = getattr(m, "A_b_log" if sfx else "A_log")
+            self.dirs.append(dict(conv_w=f(conv.weight).reshape(m.d_inner, -1), conv_b=f(conv.bias), x_proj=c(xp.weight),
+                                  dt_proj=c(dtp.weight), dt_bias=f(dtp.bias), A=(-torch.exp(A_log.detach().float())).contiguous(),
+                                  D=f(getattr(m, "D_b" if sfx else "D"))))
+        cm = layer.convolution_module
+        self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
+        self.pw_w, self.pw_b = c(cm.bottleneck[0].weight.squeeze(-1)), c(cm.bottleneck[0].bias)
+        self.dw_w, self.dw_b = f(cm.conv.weight), f(cm.conv.bias)
+        self.cm_ln2 = (f(cm.after_conv[0].weight), f(cm.after_conv[0].bias), cm.after_conv[0].eps)
+        self.lin_w, self.lin_b = c(cm.after_conv[2].weight), c(cm.after_conv[2].bias)
+        self.kernel_size = cm.kernel_size
+
+    @staticmethod
+    def _ver(layer):
+        return sum(p._version for p in layer.parameters())
+
+    def stale(self, layer, dtype):
+        return dtype != self.dtype or self._ver(layer) != self.version
+
+
+def _cache(layer, dtype) -> _LayerCache:
+    c = getattr(layer, "_cm_fused_cache", None)
+    if c is None or c.stale(layer, dtype):
+        c = _LayerCache(layer, dtype)
+        layer._cm_fused_cache = c
+    return c
+
+
+def supports(layer) -> bool:
+    """The fused path covers the non-causal bidirectional (BiMamba v2) layer the ASR recipes build."""
+    from .modules.mamba.bimamba import Mamba as BiMamba
+    cm = layer.convolution_module
+    act_ok = isinstance(cm.after_conv[1], torch.nn.GELU) and isinstance(layer.ffn_module1[1].ffn[1], torch.nn.GELU)
+    return (isinstance(layer.mamba, BiMamba) and not cm.causal and cm.kernel_size == 31 and cm.dilation == 1 and act_ok
+            and layer.mamba.d_state == 16 and layer.mamba.d_conv == 4)
+
+
+def _ffn(x, y_in, p, dtype):
+    """y_in = LN(x) already computed (compute dtype) -> Linear -> GELU -> Linear (bias folded by addmm)."""
+    h = F.gelu(torch.addmm(p["b1"], y_in, p["w1"].t()))
+    return torch.addmm(p["b2"], h, p["w2"].t())
+
+
+def bimamba_fused(c: _LayerCache, h, batch, seqlen):
+    """h: LN'd input (rows, D) in the compute dtype -> mixer output (rows, D) (reference bimamba.py:192-253)."""
+    E, R, N = c.d_inner, c.dt_rank, c.d_state
+    rows = batch * seqlen
+    xz = h @ c.in_proj.t()                                               # (rows, 2E): [x | z], channels-last
+    if c.in_bias is not None:
+        xz = xz + c.in_bias
+    xz3 = xz.view(batch, seqlen, 2 * E)
+    ucat = torch.empty((batch, seqlen, 2 * E), dtype=xz.dtype, device=xz.device)
+    ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                    True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+    ycat = torch.empty_like(ucat)
+    dirs = []
+    u2 = ucat.view(rows, 2 * E)
+    for i, d in enumerate(c.dirs):
+        u = u2[:, i * E:(i + 1) * E]                                     # (rows, E) column slice
+        xdblT = d["x_proj"] @ u.t()                                      # (R+2N, rows): time contiguous per state
+        delta = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)  # (rows, E), pre-bias
+        bc = ops.alloc_bc(2 * N, batch, seqlen, xz.device)
+        bc.view(2 * N, rows).copy_(xdblT[R:])                            # fp32 B | C rows (state, batch, time)
+        dirs.append(dict(u=ucat[:, :, i * E:(i + 1) * E], delta=delta, A=d["A"], B=bc[:N], C=bc[N:], D=d["D"],
+                         delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i)))
+    ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
+    y = ycat.view(rows, 2 * E) @ c.out_cat.t()                           # 0.5*(y_f + y_b) @ W_out^T
+    if c.out_bias is not None:
+        y = y + c.out_bias
+    if c.gamma is not None:
+        y = y * c.gamma.to(y.dtype)
+    return y
+
+
+def layer_forward(layer, x, batch, seqlen, dtype, next_ln=None, final_ln=None):
+    """One ConmambaEncoderLayer on the fp32 residual stream x (rows, D), in place.
+    Returns (x, h) where h = next_ln(x) in the compute dtype if next_ln is given."""
+    c = _cache(layer, dtype)
+    D = x.shape[-1]
+    _, h = ops.add_layernorm(x, None, norm2=c.ffn1["ln"], out_dtype=dtype)                   # LN of ffn_module1
+    y = _ffn(x, h, c.ffn1, dtype)
+    _, h = ops.add_layernorm(x, y, 0.5, x_out=x, norm2=c.norm1, out_dtype=dtype)              # x += 0.5 ffn1 ; norm1
+    y = bimamba_fused(c, h, batch, seqlen)
+    _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)              # x += mamba ; conv-module LN
+    pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)                       # pointwise conv D -> 2D
+    g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2])
+    y = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
+    _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.ffn2["ln"], out_dtype=dtype)         # x += conv ; LN of ffn_module2
+    y = _ffn(x, h, c.ffn2, dtype)
+    # x = norm2(x + 0.5 ffn2); optionally chain the encoder's final norm, and the next layer's first LN
+    n1 = c.norm2
+    if final_ln is not None:
+        ops.add_layernorm(x, y, 0.5, x_out=x, norm1=n1, want_out=False)
+        _, out = ops.add_layernorm(x, None, norm2=final_ln, out_dtype=torch.float32)
+        return out, None
+    ops.add_layernorm(x, y, 0.5, x_out=x, norm1=n1, want_out=False)
+    return x, None
+
+
+@torch.no_grad()
+def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None):
+    """ConmambaEncoder.forward (eval, no grad) through the fused path: src (B, T, D) -> (B, T, D) fp32."""
+    if dtype is None:
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+    batch, seqlen, D = src.shape
+    with torch.autocast("cuda", enabled=False):
+        x = src.detach().float().reshape(batch * seqlen, D).contiguous().clone()
+        n = len(encoder.layers)
+        fin = (encoder.norm.norm.weight.detach().float(), encoder.norm.norm.bias.detach().float(), encoder.norm.norm.eps)
+        out = x
+        for i, layer in enumerate(encoder.layers):
+            out, _ = layer_forward(layer, x, batch, seqlen, dtype, final_ln=fin if i == n - 1 else None)
+        return out.view(batch, seqlen, D)

@@ -102,6 +102,10 @@ class ConmambaEncoder(nn.Module):
         self.norm = LayerNorm(d_model, eps=FINAL_NORM_EPS)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None):
+        if (not torch.is_grad_enabled()) and (not self.training) and src.is_cuda and dynchunktrain_config is None:
+            from .. import fused
+            if all(fused.supports(layer) for layer in self.layers):
+                return fused.encoder_forward(self, src), None            # fused channels-last inference path
         out = src
         for layer in self.layers:
             out = layer(out, src_mask=src_mask, src_key_padding_mask=src_key_padding_mask, pos_embs=pos_embs,

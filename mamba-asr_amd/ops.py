@@ -198,3 +198,144 @@ def causal_conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx: Optiona
     a.stream = _stream()
     _launch("cm_causal_conv1d_bwd", N.lib().cm_causal_conv1d_bwd, a, units=b * l)
     return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------
+# channels-last ops (the fused BiMamba path)
+# ------------------------------------------------------------------------------------------
+def _rows_ok(t: torch.Tensor, what: str):
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise RuntimeError(f"{what} must be (batch, seqlen, dim) with the channel axis contiguous")
+
+
+def alloc_bc(nrows: int, batch: int, seqlen: int, device) -> torch.Tensor:
+    """(nrows, batch, seqlen) fp32 buffer whose storage is readable 16 steps past the end, as
+    cm_scan_cl_fwd requires of B/C (scalar loads fetch whole 16-step groups)."""
+    flat = torch.zeros(nrows * batch * seqlen + 16, dtype=torch.float32, device=device)
+    return flat[: nrows * batch * seqlen].view(nrows, batch, seqlen)
+
+
+def scan_cl_fwd(directions, z=None, delta_softplus=True):
+    """Channels-last selective scan, 1 or 2 directions in one launch (cm_scan_cl_fwd).
+
+    ``directions``: list of dicts with u, delta (batch, seqlen, dim), A (dim, 16), B, C (16, batch, seqlen) fp32
+    time-contiguous (see alloc_bc), D, delta_bias (dim) or None, out (batch, seqlen, dim) view or None, reverse.
+    Returns the list of out tensors."""
+    if not 1 <= len(directions) <= 2:
+        raise RuntimeError("1 or 2 directions")
+    u0 = directions[0]["u"]
+    _dev_check(u0, z)
+    _rows_ok(u0, "u")
+    b, l, d = u0.shape
+    a = N.ScanClArgs()
+    a.batch, a.seqlen, a.dim, a.dstate = b, l, d, 16
+    a.io_dtype, a.delta_softplus, a.ndir = _DT[u0.dtype], int(bool(delta_softplus)), len(directions)
+    keep = []
+    if z is not None:
+        _rows_ok(z, "z")
+        a.z, a.z_bs, a.z_ts = _ptr(z), z.stride(0), z.stride(1)
+    outs = []
+    for i, dd in enumerate(directions):
+        u, delta = dd["u"], dd["delta"]
+        _dev_check(u, delta, dd["A"], dd["B"], dd["C"])
+        _rows_ok(u, "u"), _rows_ok(delta, "delta")
+        if u.dtype != u0.dtype or delta.dtype != u0.dtype or (z is not None and z.dtype != u0.dtype):
+            raise RuntimeError("u, delta, z must share one dtype")
+        Bm, Cm = dd["B"], dd["C"]
+        if Bm.dtype != torch.float32 or Bm.stride(2) != 1 or Bm.stride() != Cm.stride() or Bm.shape != (16, b, l):
+            raise RuntimeError("B/C must be fp32 (16, batch, seqlen), time-contiguous, with equal strides")
+        A, D, bias = _f32c(dd["A"]), _f32c(dd.get("D")), _f32c(dd.get("delta_bias"))
+        out = dd.get("out")
+        if out is None:
+            out = torch.empty((b, l, d), dtype=u.dtype, device=u.device)
+        _rows_ok(out, "out")
+        keep += [A, D, bias]
+        x = a.dir[i]
+        x.u, x.delta, x.A, x.B, x.C, x.D, x.delta_bias, x.out = (_ptr(u), _ptr(delta), _ptr(A), _ptr(Bm), _ptr(Cm),
+                                                                   _ptr(D), _ptr(bias), _ptr(out))
+        x.u_bs, x.u_ts, x.delta_bs, x.delta_ts = u.stride(0), u.stride(1), delta.stride(0), delta.stride(1)
+        x.out_bs, x.out_ts = out.stride(0), out.stride(1)
+        x.bc_ns, x.bc_bs = Bm.stride(0), Bm.stride(1)
+        x.reverse_time = int(bool(dd.get("reverse", False)))
+        outs.append(out)
+    a.stream = _stream()
+    _launch("cm_scan_cl_fwd", N.lib().cm_scan_cl_fwd, a, units=b * l * len(directions))
+    return outs
+
+
+def conv_cl_fwd(x, weight_f, bias_f, weight_b=None, bias_b=None, silu=True, out_f=None, out_b=None):
+    """Channels-last depthwise conv (+SiLU) for one or both BiMamba directions in one pass (cm_conv_cl_fwd).
+    x (batch, seqlen, dim) view; weights (dim, 4); returns (y_fwd, y_bwd or None)."""
+    _dev_check(x, weight_f, bias_f, weight_b, bias_b)
+    _rows_ok(x, "x")
+    b, l, d = x.shape
+    wf, bf, wb, bb = _f32c(weight_f), _f32c(bias_f), _f32c(weight_b), _f32c(bias_b)
+    if out_f is None:
+        out_f = torch.empty((b, l, d), dtype=x.dtype, device=x.device)
+    if wb is not None and out_b is None:
+        out_b = torch.empty((b, l, d), dtype=x.dtype, device=x.device)
+    a = N.ConvClArgs()
+    a.batch, a.seqlen, a.dim, a.width, a.io_dtype, a.silu = b, l, d, wf.shape[1], _DT[x.dtype], int(bool(silu))
+    a.x, a.weight_f, a.bias_f, a.weight_b, a.bias_b = _ptr(x), _ptr(wf), _ptr(bf), _ptr(wb), _ptr(bb)
+    a.y_fwd, a.y_bwd = _ptr(out_f), _ptr(out_b if wb is not None else None)
+    a.x_bs, a.x_ts, a.yf_bs, a.yf_ts = x.stride(0), x.stride(1), out_f.stride(0), out_f.stride(1)
+    if wb is not None:
+        a.yb_bs, a.yb_ts = out_b.stride(0), out_b.stride(1)
+    a.stream = _stream()
+    _launch("cm_conv_cl_fwd", N.lib().cm_conv_cl_fwd, a, units=b * l)
+    return out_f, (out_b if wb is not None else None)
+
+
+def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_dtype=None, want_out=True):
+    """r = x + alpha*y; r1 = LN1(r) if norm1 else r; x_out <- r1 (fp32, may alias x); out = LN2(r1) if norm2 else r1.
+    x (rows.., dim) fp32 contiguous; norm = (weight, bias, eps).  Returns (x_out or None, out or None)."""
+    _dev_check(x, y)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("add_layernorm: x must be contiguous fp32")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    a = N.AddLnArgs()
+    a.rows, a.dim = rows, d
+    keep = []
+    if y is not None:
+        if not y.is_contiguous() or y.shape != x.shape:
+            raise RuntimeError("add_layernorm: y must be contiguous with x's shape")
+        a.y, a.y_dtype = _ptr(y), _DT[y.dtype]
+    a.alpha = float(alpha)
+    if norm1 is not None:
+        g, bt = _f32c(norm1[0]), _f32c(norm1[1])
+        keep += [g, bt]
+        a.g1, a.b1, a.eps1 = _ptr(g), _ptr(bt), float(norm1[2])
+    if norm2 is not None:
+        g, bt = _f32c(norm2[0]), _f32c(norm2[1])
+        keep += [g, bt]
+        a.g2, a.b2, a.eps2 = _ptr(g), _ptr(bt), float(norm2[2])
+    out = None
+    if want_out:
+        od = out_dtype or torch.bfloat16
+        out = torch.empty(x.shape, dtype=od, device=x.device)
+        a.out, a.out_dtype = _ptr(out), _DT[od]
+    a.x = _ptr(x)
+    a.x_out = _ptr(x_out)
+    a.stream = _stream()
+    _launch("cm_add_layernorm", N.lib().cm_add_layernorm, a, units=rows)
+    return x_out, out
+
+
+def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5):
+    """(batch, seqlen, 2*dim) -> (batch, seqlen, dim): GLU, depthwise conv (k=31, same padding), LayerNorm, GELU
+    (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k)."""
+    _dev_check(inp, weight, bias, ln_weight, ln_bias)
+    if not inp.is_contiguous():
+        inp = inp.contiguous()
+    b, l, d2 = inp.shape
+    d = d2 // 2
+    w = _f32c(weight).reshape(d, -1)
+    bs, g, bt = _f32c(bias), _f32c(ln_weight), _f32c(ln_bias)
+    out = torch.empty((b, l, d), dtype=inp.dtype, device=inp.device)
+    a = N.GluDwconvArgs()
+    a.batch, a.seqlen, a.dim, a.ksize, a.io_dtype = b, l, d, w.shape[1], _DT[inp.dtype]
+    a.in_, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.out = _ptr(inp), _ptr(w), _ptr(bs), _ptr(g), _ptr(bt), float(eps), _ptr(out)
+    a.stream = _stream()
+    _launch("cm_glu_dwconv_ln_gelu", N.lib().cm_glu_dwconv_ln_gelu, a, units=b * l)
+    return out

@@ -117,3 +117,60 @@ def test_bf16_autocast_encoder_close_to_fp32(golden):
         out, _ = enc(x)
     # bf16 tolerance stated in SURVEY §8d: rtol 3e-2 / atol 5e-2 on encoder output
     torch.testing.assert_close(out.float().cpu(), g["y_enc"], rtol=3e-2, atol=5e-2)
+
+
+def test_fused_encoder_matches_reference_golden(golden):
+    """The fused channels-last inference path (mamba_asr_amd.fused) against the reference's 2-layer encoder."""
+    from mamba_asr_amd import fused
+    g = golden("g4_encoder")
+    enc = _encoder(g).eval()
+    x = g["x"].to(DEV)
+    with torch.no_grad():
+        out = fused.encoder_forward(enc, x, dtype=torch.float32)
+        close(out, g["y_enc"])
+        out2, _ = enc(x)                      # module entry point dispatches to the fused path in eval/no-grad
+        close(out2, g["y_enc"])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out3, _ = enc(x)
+    torch.testing.assert_close(out3.float().cpu(), g["y_enc"], rtol=3e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_channels_last_elementwise_ops(dtype):
+    from mamba_asr_amd import ops
+    from oracle import conmamba_oracle as O
+    gen = torch.Generator().manual_seed(11)
+    b, l, e = 2, 70, 96
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    # conv, both directions
+    x = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    wf, bf_, wb, bb = (torch.randn(e, 4, generator=gen), torch.randn(e, generator=gen), torch.randn(e, 4, generator=gen),
+                       torch.randn(e, generator=gen))
+    yf, yb = ops.conv_cl_fwd(x.to(DEV)[:, :, :e], wf.to(DEV), bf_.to(DEV), wb.to(DEV), bb.to(DEV))
+    xt = x[:, :, :e].float().transpose(1, 2)
+    rf = O.causal_conv1d(xt, wf, bf_, True, work_dtype=torch.float64).transpose(1, 2)
+    rb = O.causal_conv1d(xt.flip(-1), wb, bb, True, work_dtype=torch.float64).flip(-1).transpose(1, 2)
+    torch.testing.assert_close(yf.float().cpu(), rf.float(), **tol)
+    torch.testing.assert_close(yb.float().cpu(), rb.float(), **tol)
+    # add + two LayerNorms
+    d = 144
+    xr = torch.randn(5, 7, d, generator=gen)
+    y = torch.randn(5, 7, d, generator=gen).to(dtype)
+    g1, b1, g2, b2 = (torch.randn(d, generator=gen) for _ in range(4))
+    xo = torch.empty_like(xr).to(DEV)
+    _, out = ops.add_layernorm(xr.to(DEV), y.to(DEV), 0.5, norm1=(g1.to(DEV), b1.to(DEV), 1e-5),
+                               norm2=(g2.to(DEV), b2.to(DEV), 1e-6), x_out=xo, out_dtype=dtype)
+    r1 = torch.nn.functional.layer_norm(xr + 0.5 * y.float(), (d,), g1, b1, 1e-5)
+    r2 = torch.nn.functional.layer_norm(r1, (d,), g2, b2, 1e-6)
+    torch.testing.assert_close(xo.cpu(), r1, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.float().cpu(), r2, **tol)
+    # GLU -> depthwise conv 31 -> LN -> GELU
+    dd = 80
+    inp = torch.randn(2, 45, 2 * dd, generator=gen).to(dtype)
+    w, bs = torch.randn(dd, 1, 31, generator=gen) * 0.2, torch.randn(dd, generator=gen)
+    lg, lb = torch.randn(dd, generator=gen), torch.randn(dd, generator=gen)
+    got = ops.glu_dwconv_ln_gelu(inp.to(DEV), w.to(DEV), bs.to(DEV), lg.to(DEV), lb.to(DEV), 1e-5)
+    ref = torch.nn.functional.glu(inp.float().transpose(1, 2), dim=1)
+    ref = torch.nn.functional.conv1d(ref, w, bs, padding=15, groups=dd).transpose(1, 2)
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(ref, (dd,), lg, lb, 1e-5))
+    torch.testing.assert_close(got.float().cpu(), ref, **tol)

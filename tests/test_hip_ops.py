@@ -175,3 +175,40 @@ def test_conv_reverse_and_strided(ops, dtype, l):
     close(dw, rdw, tol[0], tol[1] * max(1.0, rdw.abs().max().item()))
     close(db, rdb, tol[0], tol[1] * max(1.0, rdb.abs().max().item()))
     assert float(dxz[:, 48:].abs().max()) == 0.0        # untouched half
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 64), (2, 5, 70)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("split", [4, 8, 16])
+def test_scan_channels_last_two_directions(ops, shape, dtype, split):
+    """cm_scan_cl_fwd: both BiMamba directions in one launch, channels-last, z / out as column slices."""
+    from mamba_asr_amd import _native
+    b, l, e = shape
+    gen = torch.Generator().manual_seed(l * 7 + e)
+    xz = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    z = xz[:, :, e:]
+    dirs, refs = [], []
+    ycat = torch.zeros(b, l, 2 * e, dtype=dtype, device=DEV)
+    for i, rev in enumerate((False, True)):
+        u = torch.randn(b, l, e, generator=gen).to(dtype)
+        dl = (torch.randn(b, l, e, generator=gen) * 0.5).to(dtype)
+        A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
+        Bm, Cm = torch.randn(16, b, l, generator=gen), torch.randn(16, b, l, generator=gen)
+        D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
+        f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
+        tr = lambda t: t.float().transpose(1, 2)           # (b, l, e) -> (b, e, l)
+        ref = O.selective_scan(f(tr(u)), f(tr(dl)), A, f(Bm.permute(1, 0, 2)), f(Cm.permute(1, 0, 2)), D, f(tr(z)),
+                               bias, True, work_dtype=torch.float64)
+        refs.append(f(ref).transpose(1, 2))
+        gB, gC = ops.alloc_bc(16, b, l, DEV), ops.alloc_bc(16, b, l, DEV)
+        gB.copy_(Bm), gC.copy_(Cm)
+        dirs.append(dict(u=u.to(DEV), delta=dl.to(DEV), A=A.to(DEV), B=gB, C=gC, D=D.to(DEV), delta_bias=bias.to(DEV),
+                         out=ycat[:, :, i * e:(i + 1) * e], reverse=rev))
+    prev = _native.lib().cm_scan_set_split(split)
+    try:
+        ops.scan_cl_fwd(dirs, z=z.to(DEV) if False else xz.to(DEV)[:, :, e:], delta_softplus=True)
+    finally:
+        _native.lib().cm_scan_set_split(prev)
+    tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
+    close(ycat[:, :, :e].float(), refs[0], *tol)
+    close(ycat[:, :, e:].float(), refs[1], *tol)

@@ -65,6 +65,20 @@ def main():
         ms = timeit(both)
         print(f"scan_fwd both directions on 2 streams, split={split}: {ms*1e3:8.1f} us  {2*bytes_fwd/ms/1e6:8.1f} GB/s")
     lib.cm_scan_set_split(0)
+    # channels-last, both directions in one launch
+    ucl, dcl = u.transpose(1, 2).contiguous(), delta.transpose(1, 2).contiguous()
+    xz = torch.randn(b, l, 2 * e, device=dev, generator=g).to(dt)
+    Bcl, Ccl = ops.alloc_bc(16, b, l, dev), ops.alloc_bc(16, b, l, dev)
+    Bcl.normal_(generator=g), Ccl.normal_(generator=g)
+    ycat = torch.empty(b, l, 2 * e, device=dev, dtype=dt)
+    dirs = [dict(u=ucl, delta=dcl, A=A, B=Bcl, C=Ccl, D=D, delta_bias=bias, out=ycat[:, :, i * e:(i + 1) * e], reverse=bool(i))
+            for i in range(2)]
+    for split in (4, 8, 16):
+        lib.cm_scan_set_split(split)
+        ms = timeit(lambda: ops.scan_cl_fwd(dirs, z=xz[:, :, e:]))
+        print(f"scan_cl_fwd both directions one launch, lanes/channel={split:2d}: {ms*1e3:8.1f} us  {2*bytes_fwd/ms/1e6:8.1f} GB/s "
+              f"= {2*bytes_fwd/ms/1e6/8000*100:5.1f}% of 8 TB/s")
+    lib.cm_scan_set_split(0)
     _, x, _ = ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False)
     dout = torch.randn(b, e, l, device=dev, generator=g).to(dt)
     for split in (4, 8, 16):
