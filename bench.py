@@ -127,16 +127,16 @@ def main():
             step()
         torch.cuda.synchronize()
         log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
-        scans = [(e0.elapsed_time(e1), units) for name, e0, e1, units in log if name == "cm_selective_scan_fwd"]
+        scans = [(e0.elapsed_time(e1), units) for name, e0, e1, units in log if name == "cm_scan_cl_fwd"]
         if scans:
             e_inner, n_state, s = cfg.expand * cfg.d_model, cfg.d_state, (2 if amp is not None else 4)
             avg_ms = sum(t for t, _ in scans) / len(scans)
-            units = scans[0][1]                                      # scan steps (batch * T) per launch
-            alg_bytes = units * (4 * e_inner + 2 * n_state) * s      # (4E+2N)*s per scan step
+            units = scans[0][1]                                      # scan steps (batch * T * directions) per launch
+            alg_bytes = units * (4 * e_inner + 2 * n_state) * s      # (4E+2N)*s per scan step per direction
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "scan_fwd_kernel (cm_selective_scan_fwd)", "avg_launch_us": round(avg_ms * 1e3, 1),
+                    "kernel": "scan_cl_fwd_kernel (cm_scan_cl_fwd: both BiMamba directions per launch)", "avg_launch_us": round(avg_ms * 1e3, 1),
                     "launches_per_step": len(scans) // 3, "alg_bytes_per_launch": alg_bytes}
 
     base = None

@@ -1,0 +1,136 @@
+"""Brain-style training loop with the hooks the reference's recipes override (train_CTC.py:164-718 subclasses
+speechbrain.core.Brain: compute_forward, compute_objectives, on_stage_start/end, on_fit_batch_end) and the
+fit_batch semantics SURVEY.md Appendix A records for speechbrain 1.0.0: bf16 autocast over forward+loss,
+(loss / accum).backward(), gradient exchange only on stepping micro-batches, clip_grad_norm_, non-finite skip,
+optimizer step, zero_grad(set_to_none=True).  speechbrain itself is not installable here; this is the part of its
+surface the ConMamba recipes touch."""
+from __future__ import annotations
+
+import enum
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+from .ddp import GradAllReducer
+
+
+class Stage(enum.Enum):
+    TRAIN = 1
+    VALID = 2
+    TEST = 3
+
+
+class Brain:
+    def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None):
+        run_opts = dict(run_opts or {})
+        self.device = torch.device(run_opts.get("device", "cuda" if torch.cuda.is_available() else "cpu"))
+        self.precision = run_opts.get("precision", (hparams or {}).get("precision", "fp32"))
+        self.grad_accumulation_factor = int(run_opts.get("grad_accumulation_factor",
+                                                         (hparams or {}).get("grad_accumulation_factor", 1)))
+        self.max_grad_norm = float(run_opts.get("max_grad_norm", (hparams or {}).get("max_grad_norm", 5.0)))
+        self.modules = torch.nn.ModuleDict(modules or {}).to(self.device)
+        self.hparams = SimpleNamespace(**(hparams or {}))
+        self.opt_class = opt_class
+        self.checkpointer = checkpointer
+        self.step = 0
+        self.optimizer_step = 0
+        self.avg_train_loss = 0.0
+        self.optimizer = None
+        self.reducer: Optional[GradAllReducer] = None
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    # ---- hooks to override ---------------------------------------------------------------
+    def compute_forward(self, batch, stage):
+        raise NotImplementedError
+
+    def compute_objectives(self, predictions, batch, stage):
+        raise NotImplementedError
+
+    def on_stage_start(self, stage, epoch=None):
+        pass
+
+    def on_stage_end(self, stage, stage_loss, epoch=None):
+        pass
+
+    def on_fit_batch_end(self, batch, outputs, loss, should_step):
+        pass
+
+    def on_fit_start(self):
+        params = [p for p in self.modules.parameters() if p.requires_grad]
+        if self.opt_class is not None and self.optimizer is None:
+            self.optimizer = self.opt_class(params)
+        if self.distributed and self.reducer is None:
+            self.reducer = GradAllReducer(params)
+
+    # ---- the loop ---------------------------------------------------------------------------
+    def _autocast(self):
+        if self.precision == "bf16":
+            return torch.autocast(self.device.type, dtype=torch.bfloat16)
+        if self.precision == "fp16":
+            return torch.autocast(self.device.type, dtype=torch.float16)
+        return torch.autocast(self.device.type, enabled=False)
+
+    def fit_batch(self, batch):
+        should_step = (self.step + 1) % self.grad_accumulation_factor == 0
+        sync = self.reducer.no_sync() if (self.reducer is not None and not should_step) else _null()
+        with sync:
+            with self._autocast():
+                outputs = self.compute_forward(batch, Stage.TRAIN)
+                loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+            (loss / self.grad_accumulation_factor).backward()
+        if should_step:
+            if self.reducer is not None:
+                self.reducer.finish()
+            params = [p for p in self.modules.parameters() if p.grad is not None]
+            norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            if torch.isfinite(norm) and torch.isfinite(loss):
+                self.optimizer.step()
+                self.optimizer_step += 1
+            self.optimizer.zero_grad(set_to_none=True)
+        self.step += 1
+        self.on_fit_batch_end(batch, outputs, loss, should_step)
+        return loss.detach()
+
+    def evaluate_batch(self, batch, stage):
+        with torch.no_grad(), self._autocast():
+            out = self.compute_forward(batch, stage)
+            return self.compute_objectives(out, batch, stage).detach()
+
+    def fit(self, epoch_counter, train_set, valid_set=None):
+        self.on_fit_start()
+        for epoch in epoch_counter:
+            self.on_stage_start(Stage.TRAIN, epoch)
+            self.modules.train()
+            total, n = 0.0, 0
+            for batch in train_set:
+                total += float(self.fit_batch(batch))
+                n += 1
+            self.avg_train_loss = total / max(n, 1)
+            self.on_stage_end(Stage.TRAIN, self.avg_train_loss, epoch)
+            if valid_set is not None:
+                self.on_stage_start(Stage.VALID, epoch)
+                self.modules.eval()
+                vt, vn = 0.0, 0
+                for batch in valid_set:
+                    vt += float(self.evaluate_batch(batch, Stage.VALID))
+                    vn += 1
+                self.on_stage_end(Stage.VALID, vt / max(vn, 1), epoch)
+
+    def evaluate(self, test_set, **unused):
+        self.on_stage_start(Stage.TEST, None)
+        self.modules.eval()
+        total, n = 0.0, 0
+        for batch in test_set:
+            total += float(self.evaluate_batch(batch, Stage.TEST))
+            n += 1
+        self.on_stage_end(Stage.TEST, total / max(n, 1), None)
+        return total / max(n, 1)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

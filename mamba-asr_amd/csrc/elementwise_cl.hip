@@ -263,7 +263,7 @@ extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
     CM_REQUIRE(a.dim % n == 0 && ok(a.x, a.x_bs, a.x_ts) && ok(a.y_fwd, a.yf_bs, a.yf_ts) && ok(a.y_bwd, a.yb_bs, a.yb_ts),
                CM_EALIGN, "conv_cl_fwd: dim and strides must be multiples of %d elements, pointers 16-byte aligned", n);
     const int vpr = a.dim / n;
-    const int tc = 32;
+    const int tc = 8;
     const int64_t threads = (int64_t)a.batch * ((a.seqlen + tc - 1) / tc) * vpr;
     dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);

@@ -211,8 +211,10 @@ def _rows_ok(t: torch.Tensor, what: str):
 def alloc_bc(nrows: int, batch: int, seqlen: int, device) -> torch.Tensor:
     """(nrows, batch, seqlen) fp32 buffer whose storage is readable 16 steps past the end, as
     cm_scan_cl_fwd requires of B/C (scalar loads fetch whole 16-step groups)."""
-    flat = torch.zeros(nrows * batch * seqlen + 16, dtype=torch.float32, device=device)
-    return flat[: nrows * batch * seqlen].view(nrows, batch, seqlen)
+    n = nrows * batch * seqlen
+    flat = torch.empty(n + 16, dtype=torch.float32, device=device)
+    flat[n:].zero_()                                     # the readable tail must be finite
+    return flat[:n].view(nrows, batch, seqlen)
 
 
 def scan_cl_fwd(directions, z=None, delta_softplus=True):

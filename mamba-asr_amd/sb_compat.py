@@ -214,9 +214,14 @@ class _ConvLayer(nn.Module):
 
     def forward(self, x):                         # x: (b, t, f, c) channels-last like speechbrain
         p = self.kernel // 2
-        y = F.pad(x.permute(0, 3, 1, 2), (p, p, p, p), mode="reflect")
-        y = self.conv(y).permute(0, 2, 3, 1)
-        return self.drop(self.act(self.norm(y)).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        # logical NCHW view over the NHWC bytes (torch channels_last): conv, LayerNorm over (f, c) and the
+        # activation all run without a layout copy
+        y = F.pad(x.permute(0, 3, 1, 2), (p, p, p, p), mode="reflect").contiguous(memory_format=torch.channels_last)
+        y = self.conv(y).permute(0, 2, 3, 1)                       # (b, t', f', c) view, contiguous for channels_last
+        y = self.act(self.norm(y))
+        if self.training and self.drop.p > 0:
+            y = self.drop(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        return y
 
 
 class ConvolutionFrontEnd(nn.Module):

@@ -1,0 +1,87 @@
+"""World-size-2 gloo test (CPU) of the data-parallel gradient exchange (mamba_asr_amd.ddp): bucketed async
+all-reduce launched from autograd hooks == mean of the two ranks' gradients; no_sync leaves gradients local and
+accumulates; the Brain loop steps once per grad_accumulation_factor micro-batches."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.GELU(),
+                               torch.nn.Linear(64, 5))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mamba_asr_amd.ddp import GradAllReducer
+    from mamba_asr_amd.brain import Brain
+    model = _model()
+    if rank == 1:                                   # start from different weights: the reducer must broadcast rank 0's
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    red = GradAllReducer(model.parameters(), bucket_mb=0.004)      # several buckets
+    assert len(red.buckets) > 2
+    ref = _model()
+    for p, r in zip(model.parameters(), ref.parameters()):
+        assert torch.equal(p, r)
+    g = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 5, generator=g)
+    # accumulation micro-batch: local only
+    with red.no_sync():
+        ((model(x) - y) ** 2).mean().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    # stepping micro-batch: exchanged
+    ((model(x) - y) ** 2).mean().backward()
+    red.finish()
+    # expected: mean over ranks of (2 * local grad)
+    both = []
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        xr, yr = torch.randn(8, 16, generator=gr), torch.randn(8, 5, generator=gr)
+        m = _model()
+        (2 * ((m(xr) - yr) ** 2).mean()).backward()
+        both.append([p.grad for p in m.parameters()])
+    ok = all(torch.allclose(p.grad, (a + b) / 2, atol=1e-6) for p, a, b in zip(model.parameters(), *both))
+    ok = ok and all(torch.allclose(l * 2, a, atol=1e-6) for l, a in zip(local, both[rank]))
+
+    # Brain loop: 4 micro-batches, accumulation 2 -> 2 optimizer steps, identical weights on both ranks afterwards
+    class B(Brain):
+        def compute_forward(self, batch, stage):
+            return self.modules["net"](batch[0])
+
+        def compute_objectives(self, pred, batch, stage):
+            return ((pred - batch[1]) ** 2).mean()
+
+    brain = B({"net": _model()}, opt_class=lambda ps: torch.optim.SGD(ps, lr=0.1),
+              hparams={"grad_accumulation_factor": 2}, run_opts={"device": "cpu"})
+    data = [(torch.randn(4, 16, generator=g), torch.randn(4, 5, generator=g)) for _ in range(4)]
+    brain.fit(range(1), data)
+    flat = torch.cat([p.detach().reshape(-1) for p in brain.modules.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = ok and brain.optimizer_step == 2 and torch.allclose(gathered[0], gathered[1], atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
