@@ -233,8 +233,8 @@ typedef struct cm_add_ln_args {
     int32_t dim;
     int32_t y_dtype;             /* dtype of y (CM_BF16 / CM_F32)        */
     int32_t out_dtype;           /* dtype of out                          */
-    int32_t pad_;
-    const float *x;              /* (rows, dim) fp32                      */
+    int32_t out_act;             /* activation applied to `out`: 0 none, 1 LeakyReLU(0.01) */
+    const float *x;              /* (rows, dim) fp32, or NULL (treated as zeros)            */
     const void  *y;              /* (rows, dim) or NULL                   */
     float alpha;
     float eps1, eps2;
@@ -268,6 +268,29 @@ typedef struct cm_glu_dwconv_args {
 } cm_glu_dwconv_args;
 
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * First block of the CNN front end (speechbrain ConvolutionFrontEnd as configured at reference
+ * hparams/CTC/conmamba_large.yaml:187-194): Conv2d(1 -> C, 3x3, stride 2 in time and frequency, reflect
+ * 'same' padding) -> LayerNorm over (freq, channel) -> LeakyReLU(0.01), fused, channels-last.
+ *   in : feats (batch, T, F) fp32
+ *   out: (batch, T1 + 2*pad_out, F1 + 2*pad_out, C) io_dtype, T1 = ceil(T/2), F1 = ceil(F/2); with pad_out = 1 the
+ *        reflect border the NEXT 3x3 stride-2 block needs is written as well, so that block runs unpadded.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_cnn_block1_args {
+    int32_t batch, T, F, C;
+    int32_t io_dtype;            /* output dtype                                           */
+    int32_t pad_out;             /* 0 or 1                                                 */
+    const float *feats;          /* (batch, T, F)                                          */
+    const float *weight;         /* (C, 1, 3, 3)                                           */
+    const float *bias;           /* (C)                                                    */
+    const float *ln_g, *ln_b;    /* (F1, C)                                                */
+    float eps, slope;
+    void *out;
+    void *stream;
+} cm_cnn_block1_args;
+
+int cm_cnn_block1(const cm_cnn_block1_args *args);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ class ConvClArgs(C.Structure):
 
 class AddLnArgs(C.Structure):
     _fields_ = [
-        ("rows", i64), ("dim", i32), ("y_dtype", i32), ("out_dtype", i32), ("pad_", i32),
+        ("rows", i64), ("dim", i32), ("y_dtype", i32), ("out_dtype", i32), ("out_act", i32),
         ("x", fp), ("y", vp), ("alpha", C.c_float), ("eps1", C.c_float), ("eps2", C.c_float), ("pad2_", i32),
         ("g1", fp), ("b1", fp), ("g2", fp), ("b2", fp), ("x_out", fp), ("out", vp), ("stream", vp),
     ]
@@ -92,6 +92,14 @@ class GluDwconvArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("pad_", i32),
         ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
+        ("out", vp), ("stream", vp),
+    ]
+
+
+class CnnBlock1Args(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("T", i32), ("F", i32), ("C", i32), ("io_dtype", i32), ("pad_out", i32),
+        ("feats", fp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("slope", C.c_float),
         ("out", vp), ("stream", vp),
     ]
 
@@ -110,6 +118,7 @@ SYMBOLS = [
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
+    ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
 ]
 
 _lib = None

@@ -82,6 +82,11 @@ class ConMambaASR(nn.Module):
 
     def encode(self, wavs, wav_lens, epoch=0, augment=None):
         """wav (B, samples) -> encoder output (B, ceil(T/4), d_model): the path the headline metric times."""
+        if (not torch.is_grad_enabled()) and (not self.training) and wavs.is_cuda and augment is None \
+                and self.normalize.count > 0:
+            from . import fused
+            if all(fused.supports(layer) for layer in self.Transformer.encoder.layers):
+                return fused.asr_encode(self, wavs, wav_lens)                    # native inference path
         src = self.CNN(self.features(wavs, wav_lens, epoch, augment))
         return self.Transformer.encode(src, wav_lens)
 

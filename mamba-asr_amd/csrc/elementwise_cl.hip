@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const cm_add_ln_args p) {
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
-            const float4 xv = *reinterpret_cast<const float4 *>(p.x + row * D + c);
+            float4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (p.x) xv = *reinterpret_cast<const float4 *>(p.x + row * D + c);
             r[i][0] = xv.x; r[i][1] = xv.y; r[i][2] = xv.z; r[i][3] = xv.w;
             if (p.y) {
                 const YT *yp = reinterpret_cast<const YT *>(p.y) + row * D + c;
@@ -173,7 +174,11 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const cm_add_ln_args p) {
             const int c = (i * 64 + lane) * 4;
             if (c < D) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm_elem<OT>::store(op + c + j, r[i][j]);
+                for (int j = 0; j < 4; ++j) {
+                    float v = r[i][j];
+                    if (p.out_act == 1) v = v > 0.f ? v : 0.01f * v;
+                    cm_elem<OT>::store(op + c + j, v);
+                }
             }
         }
     }
@@ -249,7 +254,97 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CNN block 1: conv 3x3 stride 2 (1 input channel) + LayerNorm(F1*C) + LeakyReLU, one workgroup per padded
+// output time row.  The three input rows live in LDS; each thread produces F1*C/256 outputs, the row statistics
+// are a block reduction, and the row (plus its reflected frequency border) is written once.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+template <typename OT, int MAXPT>
+__global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_args p, int T1, int F1) {
+    __shared__ float rows[3][128 + 2];                 // input rows 2*t1-1 .. 2*t1+1 with reflect padding in F (F <= 128)
+    __shared__ float red[2][4];
+    const int C = p.C, F = p.F, T = p.T;
+    const int P = p.pad_out;
+    const int tp = blockIdx.x, b = blockIdx.y;
+    const int t1 = reflect_idx(tp - P, T1);            // source output row (reflect border of the padded output)
+    const float *feats = p.feats + (int64_t)b * T * F;
+    for (int i = threadIdx.x; i < 3 * (F + 2); i += blockDim.x) {
+        const int r = i / (F + 2), f = i % (F + 2);
+        const int tin = reflect_idx(2 * t1 + r - 1, T), fin = reflect_idx(f - 1, F);
+        rows[r][f] = feats[(int64_t)tin * F + fin];
+    }
+    __syncthreads();
+    const int n = F1 * C;
+    float v[MAXPT];
+    float s = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPT; ++i) {
+        const int o = threadIdx.x + i * 256;           // o = f1 * C + c  (channel fastest: coalesced stores)
+        v[i] = 0.f;
+        if (o < n) {
+            const int f1 = o / C, c = o % C;
+            float acc = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) acc = fmaf(p.weight[c * 9 + dt * 3 + df], rows[dt][2 * f1 + df], acc);
+            v[i] = acc;
+            s += acc;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+#pragma unroll
+    for (int i = 0; i < MAXPT; ++i) {
+        const int o = threadIdx.x + i * 256;
+        if (o < n) { const float d = v[i] - mean; sq += d * d; }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n + p.eps);
+    OT *out = reinterpret_cast<OT *>(p.out) + ((int64_t)b * (T1 + 2 * P) + tp) * (F1 + 2 * P) * C;
+#pragma unroll
+    for (int i = 0; i < MAXPT; ++i) {
+        const int o = threadIdx.x + i * 256;
+        if (o < n) {
+            const int f1 = o / C, c = o % C;
+            float y = (v[i] - mean) * rstd * p.ln_g[o] + p.ln_b[o];
+            y = y > 0.f ? y : p.slope * y;
+            cm_elem<OT>::store(out + (f1 + P) * C + c, y);
+            if (P) {                                   // reflected frequency border: fp = 0 <- f1 = 1, fp = F1+1 <- f1 = F1-2
+                if (f1 == 1) cm_elem<OT>::store(out + c, y);
+                if (f1 == F1 - 2) cm_elem<OT>::store(out + (F1 + 1) * C + c, y);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int cm_cnn_block1(const cm_cnn_block1_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "cnn_block1: args is NULL");
+    const cm_cnn_block1_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.T > 1 && a.F > 1 && a.C > 0 && a.feats && a.weight && a.ln_g && a.ln_b && a.out, CM_EINVAL,
+               "cnn_block1: bad sizes or NULL tensor");
+    CM_REQUIRE(a.F <= 128, CM_EUNSUPPORTED, "cnn_block1: F %d unsupported (<= 128)", a.F);
+    CM_REQUIRE(a.pad_out == 0 || a.pad_out == 1, CM_EINVAL, "cnn_block1: pad_out must be 0 or 1");
+    const int T1 = (a.T + 1) / 2, F1 = (a.F + 1) / 2;
+    CM_REQUIRE(F1 * a.C <= 16 * 256 && T1 >= 3 && F1 >= 3, CM_EUNSUPPORTED, "cnn_block1: F1*C = %d unsupported (<= 4096)", F1 * a.C);
+    dim3 grid(T1 + 2 * a.pad_out, a.batch);
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    const int pt = (F1 * a.C + 255) / 256;
+    auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a, T1, F1); };
+    if (a.io_dtype == CM_BF16) { if (pt <= 10) launch(cnn_block1_kernel<cm_bf16, 10>); else launch(cnn_block1_kernel<cm_bf16, 16>); }
+    else if (a.io_dtype == CM_F32) { if (pt <= 10) launch(cnn_block1_kernel<float, 10>); else launch(cnn_block1_kernel<float, 16>); }
+    else { cm_set_error("cnn_block1: unsupported dtype %d", a.io_dtype); return CM_EUNSUPPORTED; }
+    return cm_launch_status("cm_cnn_block1");
+}
 
 extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "conv_cl_fwd: args is NULL");
@@ -276,7 +371,7 @@ extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
 extern "C" int cm_add_layernorm(const cm_add_ln_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "add_layernorm: args is NULL");
     const cm_add_ln_args &a = *args;
-    CM_REQUIRE(a.rows > 0 && a.dim > 0 && a.x, CM_EINVAL, "add_layernorm: bad sizes / x is NULL");
+    CM_REQUIRE(a.rows > 0 && a.dim > 0 && (a.x || a.y), CM_EINVAL, "add_layernorm: bad sizes / x and y both NULL");
     CM_REQUIRE(a.dim % 4 == 0 && a.dim <= 1024, CM_EUNSUPPORTED, "add_layernorm: dim %d unsupported (multiple of 4, <= 1024)", a.dim);
     CM_REQUIRE((!a.g1 || a.b1) && (!a.g2 || a.b2), CM_EINVAL, "add_layernorm: LayerNorm weight without bias");
     dim3 grid((unsigned)((a.rows + 3) / 4));

@@ -159,3 +159,46 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None):
         for i, layer in enumerate(encoder.layers):
             out, _ = layer_forward(layer, x, batch, seqlen, dtype, final_ln=fin if i == n - 1 else None)
         return out.view(batch, seqlen, D)
+
+
+# ------------------------------------------------------------------------------------------------
+# front end + encoder: the whole path the headline metric times (reference train_CTC.py:285-298)
+# ------------------------------------------------------------------------------------------------
+def _frontend_cache(model, dtype):
+    c = getattr(model, "_cm_frontend_cache", None)
+    ver = sum(p._version for p in model.CNN.parameters()) + sum(p._version for p in model.Transformer.custom_src_module.parameters())
+    if c is None or c["dtype"] != dtype or c["ver"] != ver:
+        b0, b1 = model.CNN.blocks
+        lin = model.Transformer.custom_src_module.layers[0].w
+        c = dict(dtype=dtype, ver=ver,
+                 w2=b1.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last),
+                 b2=b1.conv.bias.detach().to(dtype),
+                 ln2=(b1.norm.norm.weight.detach().float().reshape(-1).contiguous(),
+                      b1.norm.norm.bias.detach().float().reshape(-1).contiguous(), b1.norm.norm.eps),
+                 lin_w=lin.weight.detach().to(dtype).contiguous(), lin_b=lin.bias.detach().to(dtype))
+        model._cm_frontend_cache = c
+    return c
+
+
+@torch.no_grad()
+def asr_encode(model, wavs, wav_lens, dtype: Optional[torch.dtype] = None):
+    """ConMambaASR.encode in eval mode through native kernels: Fbank (torch.stft/rocFFT + mel GEMM) -> global
+    normalisation -> cm_cnn_block1 (conv+LN+LeakyReLU, next block's reflect border included) -> library conv
+    (64->32, 3x3, stride 2, channels-last, unpadded) -> cm_add_layernorm(LN + LeakyReLU) -> src Linear ->
+    fused encoder.  Returns (batch, ceil(T/4), d_model) fp32."""
+    if dtype is None:
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+    with torch.autocast("cuda", enabled=False):
+        feats = model.normalize(model.compute_features(wavs), wav_lens)            # (B, T, n_mels) fp32
+        c = _frontend_cache(model, dtype)
+        b0 = model.CNN.blocks[0]
+        y1 = ops.cnn_block1(feats, b0.conv.weight, b0.conv.bias, b0.norm.norm.weight, b0.norm.norm.bias,
+                            b0.norm.norm.eps, 0.01, out_dtype=dtype, pad_out=1)     # (B, T1+2, F1+2, 64) NHWC
+        y2 = F.conv2d(y1.permute(0, 3, 1, 2), c["w2"], c["b2"], stride=2)           # channels_last in / out
+        y2 = y2.permute(0, 2, 3, 1)                                                 # (B, T2, F2, 32)
+        if not y2.is_contiguous():
+            y2 = y2.contiguous()
+        batch, t2 = y2.shape[0], y2.shape[1]
+        _, src = ops.add_layernorm(None, y2.reshape(batch * t2, -1), norm2=c["ln2"], out_dtype=dtype, out_act=1)
+        x = torch.addmm(c["lin_b"], src, c["lin_w"].t())                            # (rows, D)
+        return encoder_forward(model.Transformer.encoder, x.view(batch, t2, -1), dtype)

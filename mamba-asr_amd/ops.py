@@ -288,19 +288,21 @@ def conv_cl_fwd(x, weight_f, bias_f, weight_b=None, bias_b=None, silu=True, out_
     return out_f, (out_b if wb is not None else None)
 
 
-def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_dtype=None, want_out=True):
+def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_dtype=None, want_out=True,
+                  out_act=0):
     """r = x + alpha*y; r1 = LN1(r) if norm1 else r; x_out <- r1 (fp32, may alias x); out = LN2(r1) if norm2 else r1.
     x (rows.., dim) fp32 contiguous; norm = (weight, bias, eps).  Returns (x_out or None, out or None)."""
     _dev_check(x, y)
-    if x.dtype != torch.float32 or not x.is_contiguous():
+    ref = x if x is not None else y
+    if x is not None and (x.dtype != torch.float32 or not x.is_contiguous()):
         raise RuntimeError("add_layernorm: x must be contiguous fp32")
-    d = x.shape[-1]
-    rows = x.numel() // d
+    d = ref.shape[-1]
+    rows = ref.numel() // d
     a = N.AddLnArgs()
-    a.rows, a.dim = rows, d
+    a.rows, a.dim, a.out_act = rows, d, int(out_act)
     keep = []
     if y is not None:
-        if not y.is_contiguous() or y.shape != x.shape:
+        if not y.is_contiguous() or y.shape != ref.shape:
             raise RuntimeError("add_layernorm: y must be contiguous with x's shape")
         a.y, a.y_dtype = _ptr(y), _DT[y.dtype]
     a.alpha = float(alpha)
@@ -315,7 +317,7 @@ def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_
     out = None
     if want_out:
         od = out_dtype or torch.bfloat16
-        out = torch.empty(x.shape, dtype=od, device=x.device)
+        out = torch.empty(ref.shape, dtype=od, device=ref.device)
         a.out, a.out_dtype = _ptr(out), _DT[od]
     a.x = _ptr(x)
     a.x_out = _ptr(x_out)
@@ -340,4 +342,23 @@ def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5):
     a.in_, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.out = _ptr(inp), _ptr(w), _ptr(bs), _ptr(g), _ptr(bt), float(eps), _ptr(out)
     a.stream = _stream()
     _launch("cm_glu_dwconv_ln_gelu", N.lib().cm_glu_dwconv_ln_gelu, a, units=b * l)
+    return out
+
+
+def cnn_block1(feats, weight, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01, out_dtype=torch.bfloat16, pad_out=1):
+    """feats (batch, T, F) fp32 -> (batch, ceil(T/2) + 2*pad_out, ceil(F/2) + 2*pad_out, C): 3x3 stride-2 conv, LayerNorm
+    over (freq, channel), LeakyReLU, with the reflect border of the next 3x3 block already in place (cm_cnn_block1)."""
+    _dev_check(feats, weight, bias, ln_weight, ln_bias)
+    feats = feats.float().contiguous()
+    b, t, f = feats.shape
+    w, bs, g, bt = _f32c(weight), _f32c(bias), _f32c(ln_weight), _f32c(ln_bias)
+    cch = w.shape[0]
+    t1, f1 = (t + 1) // 2, (f + 1) // 2
+    out = torch.empty((b, t1 + 2 * pad_out, f1 + 2 * pad_out, cch), dtype=out_dtype, device=feats.device)
+    a = N.CnnBlock1Args()
+    a.batch, a.T, a.F, a.C, a.io_dtype, a.pad_out = b, t, f, cch, _DT[out_dtype], pad_out
+    a.feats, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.slope, a.out = (_ptr(feats), _ptr(w), _ptr(bs), _ptr(g), _ptr(bt),
+                                                                          float(eps), float(slope), _ptr(out))
+    a.stream = _stream()
+    _launch("cm_cnn_block1", N.lib().cm_cnn_block1, a, units=b * t)
     return out

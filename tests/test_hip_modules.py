@@ -174,3 +174,26 @@ def test_channels_last_elementwise_ops(dtype):
     ref = torch.nn.functional.conv1d(ref, w, bs, padding=15, groups=dd).transpose(1, 2)
     ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(ref, (dd,), lg, lb, 1e-5))
     torch.testing.assert_close(got.float().cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_frontend_and_encoder_match_unfused_and_oracle(dtype):
+    """ConMambaASR.encode: native inference path == module-by-module path == CPU oracle (fp32)."""
+    from mamba_asr_amd import fused
+    from mamba_asr_amd.asr import ASRConfig, ConMambaASR, synthetic_wavs, samples_for_frames
+    from oracle import conmamba_oracle as O
+    cfg = ASRConfig("tiny", d_model=64, d_ffn=128, num_encoder_layers=2, n_fft=400, seed=5)
+    model = ConMambaASR(cfg).to(DEV).eval()
+    wavs, lens = synthetic_wavs(2, samples_for_frames(203), 9, DEV)
+    with torch.no_grad():
+        feats = model.features(wavs, lens)                                  # fills the normaliser statistics
+        ref = model.Transformer.encode(model.CNN(feats), lens)               # module path (fp32)
+        got = fused.asr_encode(model, wavs, lens, dtype=dtype)
+    assert got.shape == ref.shape == (2, 51, 64)
+    if dtype == torch.float32:
+        close(got, ref, rtol=2e-3, atol=2e-4)
+        p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        want = O.asr_encode(p, wavs.cpu(), lens.cpu(), 2, p["normalize.glob_mean"], p["normalize.glob_std"], n_fft=400)
+        close(got, want, rtol=5e-3, atol=1e-3)
+    else:
+        torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)
