@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=4000, help="10 ms audio frames per utterance (L)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
     return ap.parse_args()
@@ -93,9 +94,17 @@ def main():
     wavs, lens = synthetic_wavs(a.batch, samples_for_frames(a.frames), cfg.seed + rank, dev)
     amp = torch.bfloat16 if a.dtype == "bf16" else None
 
-    def step():
+    def eager_step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp is not None):
             return model.encode(wavs, lens)
+
+    eager_step()                                            # first batch: fills the global normalisation statistics
+    if a.no_graph:
+        step = eager_step
+    else:
+        from mamba_asr_amd.fused import GraphedEncode
+        graphed = GraphedEncode(model, wavs, lens, dtype=torch.bfloat16 if amp is not None else torch.float32)
+        step = lambda: graphed()
 
     def fence():
         torch.cuda.synchronize()
@@ -124,7 +133,7 @@ def main():
     if rank == 0:
         ops.LAUNCH_LOG = []
         for _ in range(3):
-            step()
+            eager_step()                                    # eager pass: each native launch bracketed by HIP events
         torch.cuda.synchronize()
         log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
         scans = [(e0.elapsed_time(e1), units) for name, e0, e1, units in log if name == "cm_scan_cl_fwd"]
@@ -155,7 +164,8 @@ def main():
             "config": {"workload": f"{a.config}: encoder forward, {a.batch} utterances x {a.frames} frames "
                                    f"({a.frames // 4} scan steps) per GPU, random-init weights",
                        "global_batch": world * a.batch, "frames_per_utterance": a.frames,
-                       "parallelism": f"utterance shards x{world} (no collective in forward)"},
+                       "parallelism": f"utterance shards x{world} (no collective in forward)",
+                       "launch": "eager" if a.no_graph else "hipGraph replay"},
             "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
             "roofline": roof, "cpu_baseline": base,
         }

@@ -29,15 +29,26 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // conv, both directions.  One thread owns one 16-byte channel vector and walks a run of TC steps with a
 // rolling window of W rows: the newest W rows x[s-W+1..s] give y_fwd[s] and y_bwd[s-W+1].
 // ------------------------------------------------------------------------------------------------
-template <typename IO, int W>
-__global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, int vpr, int tc) {
+template <typename IO, int W, int TC>
+__global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, int vpr) {
     constexpr int N = cm_elem<IO>::kVec;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;          // flat (chunk, vector) index
-    const int nchunk = (p.seqlen + tc - 1) / tc;
+    const int nchunk = (p.seqlen + TC - 1) / TC;
     const int vec = v % vpr, chunk = (v / vpr) % nchunk, b = v / (vpr * nchunk);
     if (b >= p.batch) return;
     const int c0 = vec * N;
     const bool two = p.y_bwd != nullptr;
+    const IO *x = reinterpret_cast<const IO *>(p.x) + (int64_t)b * p.x_bs + c0;
+    IO *yf = reinterpret_cast<IO *>(p.y_fwd) + (int64_t)b * p.yf_bs + c0;
+    IO *yb = two ? reinterpret_cast<IO *>(p.y_bwd) + (int64_t)b * p.yb_bs + c0 : nullptr;
+    const int t0 = chunk * TC;
+    // rows t0-(W-1) .. t0+TC-1+(W-1): every load is issued before the first use
+    uint4 raw[TC + 2 * (W - 1)];
+#pragma unroll
+    for (int r = 0; r < TC + 2 * (W - 1); ++r) {
+        const int s = t0 - (W - 1) + r;
+        raw[r] = (s >= 0 && s < p.seqlen) ? *reinterpret_cast<const uint4 *>(x + (int64_t)s * p.x_ts) : make_uint4(0u, 0u, 0u, 0u);
+    }
     float wf[N][W], wb[N][W], bf[N], bb[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -49,48 +60,29 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, i
         bf[j] = p.bias_f ? p.bias_f[c0 + j] : 0.f;
         bb[j] = (two && p.bias_b) ? p.bias_b[c0 + j] : 0.f;
     }
-    const IO *x = reinterpret_cast<const IO *>(p.x) + (int64_t)b * p.x_bs + c0;
-    IO *yf = reinterpret_cast<IO *>(p.y_fwd) + (int64_t)b * p.yf_bs + c0;
-    IO *yb = two ? reinterpret_cast<IO *>(p.y_bwd) + (int64_t)b * p.yb_bs + c0 : nullptr;
-    const int t0 = chunk * tc, t1 = min(t0 + tc, p.seqlen);
-    float win[W][N];                                              // win[k] = x[s-(W-1)+k]
+    auto elem = [&](int r, int j) -> float {                      // row r of the window, channel j
+        alignas(16) IO tmp[N];
+        *reinterpret_cast<uint4 *>(tmp) = raw[r];
+        return cm_elem<IO>::load(&tmp[j]);
+    };
 #pragma unroll
-    for (int k = 0; k < W; ++k)
+    for (int i = 0; i < TC; ++i) {
+        const int t = t0 + i;
+        if (t >= p.seqlen) break;
+        float of[N], ob[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) win[k][j] = 0.f;
-    for (int s = t0 - (W - 1); s < t1 + (W - 1); ++s) {
+        for (int j = 0; j < N; ++j) {
+            float af = bf[j], ab = bb[j];
 #pragma unroll
-        for (int k = 0; k < W - 1; ++k)
-#pragma unroll
-            for (int j = 0; j < N; ++j) win[k][j] = win[k + 1][j];
-        if (s >= 0 && s < p.seqlen) vec8<IO>::load(x + (int64_t)s * p.x_ts, win[W - 1]);
-        else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) win[W - 1][j] = 0.f;
-        }
-        if (s >= t0 && s < t1) {                                  // causal output at s
-            float o[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float acc = bf[j];
-#pragma unroll
-                for (int k = 0; k < W; ++k) acc = fmaf(wf[j][k], win[k][j], acc);
-                o[j] = p.silu ? acc * cm_sigmoid(acc) : acc;
+            for (int k = 0; k < W; ++k) {
+                af = fmaf(wf[j][k], elem(i + k, j), af);                       // x[t-(W-1)+k]
+                ab = fmaf(wb[j][k], elem(i + 2 * (W - 1) - k, j), ab);         // x[t+(W-1)-k]
             }
-            vec8<IO>::store(yf + (int64_t)s * p.yf_ts, o);
+            of[j] = p.silu ? af * cm_sigmoid(af) : af;
+            ob[j] = p.silu ? ab * cm_sigmoid(ab) : ab;
         }
-        const int sb = s - (W - 1);                               // anti-causal output at s-(W-1)
-        if (two && sb >= t0 && sb < t1) {
-            float o[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float acc = bb[j];
-#pragma unroll
-                for (int k = 0; k < W; ++k) acc = fmaf(wb[j][k], win[W - 1 - k][j], acc);   // tap k <-> x[t+(W-1)-k]
-                o[j] = p.silu ? acc * cm_sigmoid(acc) : acc;
-            }
-            vec8<IO>::store(yb + (int64_t)sb * p.yb_ts, o);
-        }
+        vec8<IO>::store(yf + (int64_t)t * p.yf_ts, of);
+        if (two) vec8<IO>::store(yb + (int64_t)t * p.yb_ts, ob);
     }
 }
 
@@ -202,19 +194,36 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     float *co = sm + (size_t)nin * D;                             // [tt][D]
     const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * 2 * D;
     // phase 1: GLU rows -> LDS  (a = in[:, :D], gate = in[:, D:])
-    for (int idx = threadIdx.x; idx < nin * (D / 2); idx += blockDim.x) {
-        const int r = idx / (D / 2), c = (idx % (D / 2)) * 2;
-        const int t = t0 - K / 2 + r;
-        float v0 = 0.f, v1 = 0.f;
-        if (t >= 0 && t < T) {
-            const IO *row = in + (int64_t)t * 2 * D;
-            const float a0 = cm_elem<IO>::load(row + c), a1 = cm_elem<IO>::load(row + c + 1);
-            const float g0 = cm_elem<IO>::load(row + D + c), g1 = cm_elem<IO>::load(row + D + c + 1);
-            v0 = a0 * cm_sigmoid(g0);
-            v1 = a1 * cm_sigmoid(g1);
+    constexpr int NV = cm_elem<IO>::kVec;
+    if (D % NV == 0) {
+        for (int idx = threadIdx.x; idx < nin * (D / NV); idx += blockDim.x) {
+            const int r = idx / (D / NV), c = (idx % (D / NV)) * NV;
+            const int t = t0 - K / 2 + r;
+            float av[NV], gv[NV];
+            if (t >= 0 && t < T) {
+                const IO *row = in + (int64_t)t * 2 * D;
+                vec8<IO>::load(row + c, av);
+                vec8<IO>::load(row + D + c, gv);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) av[j] *= cm_sigmoid(gv[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) av[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j += 4) *reinterpret_cast<float4 *>(g + r * D + c + j) = make_float4(av[j], av[j + 1], av[j + 2], av[j + 3]);
         }
-        g[r * D + c] = v0;
-        g[r * D + c + 1] = v1;
+    } else {
+        for (int idx = threadIdx.x; idx < nin * D; idx += blockDim.x) {
+            const int r = idx / D, c = idx % D;
+            const int t = t0 - K / 2 + r;
+            float v0 = 0.f;
+            if (t >= 0 && t < T) {
+                const IO *row = in + (int64_t)t * 2 * D;
+                v0 = cm_elem<IO>::load(row + c) * cm_sigmoid(cm_elem<IO>::load(row + D + c));
+            }
+            g[r * D + c] = v0;
+        }
     }
     __syncthreads();
     // phase 2: depthwise conv along time
@@ -358,12 +367,12 @@ extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
     CM_REQUIRE(a.dim % n == 0 && ok(a.x, a.x_bs, a.x_ts) && ok(a.y_fwd, a.yf_bs, a.yf_ts) && ok(a.y_bwd, a.yb_bs, a.yb_ts),
                CM_EALIGN, "conv_cl_fwd: dim and strides must be multiples of %d elements, pointers 16-byte aligned", n);
     const int vpr = a.dim / n;
-    const int tc = 8;
+    constexpr int tc = 8;
     const int64_t threads = (int64_t)a.batch * ((a.seqlen + tc - 1) / tc) * vpr;
     dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
-    if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((conv_cl_kernel<cm_bf16, 4>), grid, dim3(256), 0, st, a, vpr, tc);
-    else if (a.io_dtype == CM_F32) hipLaunchKernelGGL((conv_cl_kernel<float, 4>), grid, dim3(256), 0, st, a, vpr, tc);
+    if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((conv_cl_kernel<cm_bf16, 4, tc>), grid, dim3(256), 0, st, a, vpr);
+    else if (a.io_dtype == CM_F32) hipLaunchKernelGGL((conv_cl_kernel<float, 4, tc>), grid, dim3(256), 0, st, a, vpr);
     else { cm_set_error("conv_cl_fwd: unsupported dtype %d", a.io_dtype); return CM_EUNSUPPORTED; }
     return cm_launch_status("cm_conv_cl_fwd");
 }
