@@ -171,17 +171,22 @@ int cm_causal_conv1d_bwd(const cm_conv_args *args);
  * ------------------------------------------------------------------------------------- */
 typedef struct cm_scan_cl_dir {
     const void  *u;          /* (batch, seqlen, dim)  conv+SiLU output                      */
-    const void  *delta;      /* (batch, seqlen, dim)  pre-bias, pre-softplus                */
+    const void  *delta;      /* (batch, seqlen, dim)  pre-bias, pre-softplus; ignored when dt_low is set */
     const float *A;          /* (dim, dstate)                                               */
     const float *B;          /* (dstate, batch, seqlen) fp32                                */
     const float *C;
+    const float *dt_low;     /* optional (dt_rank, batch, seqlen) fp32, same strides as B/C: the low-rank
+                                time-step features x_dbl[:, :dt_rank]; when given the kernel forms
+                                delta = dt_weight @ dt_low itself (the reference's dt_proj GEMM,
+                                selective_scan_interface.py:187) and no delta tensor is read          */
+    const float *dt_weight;  /* (dim, dt_rank) fp32, required with dt_low; dt_rank <= 16           */
     const float *D;          /* (dim) or NULL                                               */
     const float *delta_bias; /* (dim) or NULL                                               */
     void        *out;        /* (batch, seqlen, dim)  gated output                          */
     int64_t u_bs, u_ts, delta_bs, delta_ts, out_bs, out_ts;
     int64_t bc_ns, bc_bs;    /* state / batch strides of B and C                            */
     int32_t reverse_time;
-    int32_t pad_;
+    int32_t dt_rank;
 } cm_scan_cl_dir;
 
 typedef struct cm_scan_cl_args {
@@ -291,6 +296,33 @@ typedef struct cm_cnn_block1_args {
 } cm_cnn_block1_args;
 
 int cm_cnn_block1(const cm_cnn_block1_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogues for the ConMamba layer's projections:
+ *     acc[m, n] = sum_k A[m, k] * W[n, k]            (A: activations, W: nn.Linear weight layout)
+ *   epilogue 0:  out = acc + bias                                          -> bf16   (in_proj, pointwise conv)
+ *   epilogue 1:  out = gelu(acc + bias)   (erf form, nn.GELU default)      -> bf16   (FFN up-projection)
+ *   epilogue 2:  r = x + alpha * (acc + bias);  r1 = LN1(r) if g1 else r;  x = r1 (fp32, in place);
+ *                out = LN2(r1) if g2 (bf16, optional)                                (FFN down-projection, out_proj and
+ *                the conv-module Linear: the residual/LayerNorm seams of reference modules/Conmamba.py:638-649)
+ * Requirements: K % 64 == 0, N % 256 == 0 (epilogue 2: N == 256 so that one workgroup owns whole rows),
+ * A/W/out 16-byte aligned with leading dimensions multiples of 8 elements.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_gemm_args {
+    int32_t M, N, K;
+    int32_t epilogue;
+    const void  *A;  int64_t lda;      /* (M, K) bf16                                       */
+    const void  *W;  int64_t ldw;      /* (N, K) bf16                                       */
+    const float *bias;                 /* (N) fp32 or NULL                                  */
+    void        *out; int64_t ldo;     /* (M, N) bf16; optional for epilogue 2              */
+    float       *x;                    /* epilogue 2: (M, N) fp32 residual stream, in place */
+    float alpha, eps1, eps2;
+    int32_t pad_;
+    const float *g1, *b1, *g2, *b2;    /* epilogue 2 LayerNorm parameters (N) or NULL       */
+    void *stream;
+} cm_gemm_args;
+
+int cm_gemm_bf16(const cm_gemm_args *args);
 
 #ifdef __cplusplus
 }

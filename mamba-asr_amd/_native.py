@@ -55,9 +55,10 @@ class ConvArgs(C.Structure):
 
 class ScanClDir(C.Structure):
     _fields_ = [
-        ("u", vp), ("delta", vp), ("A", fp), ("B", fp), ("C", fp), ("D", fp), ("delta_bias", fp), ("out", vp),
+        ("u", vp), ("delta", vp), ("A", fp), ("B", fp), ("C", fp), ("dt_low", fp), ("dt_weight", fp), ("D", fp),
+        ("delta_bias", fp), ("out", vp),
         ("u_bs", i64), ("u_ts", i64), ("delta_bs", i64), ("delta_ts", i64), ("out_bs", i64), ("out_ts", i64),
-        ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("pad_", i32),
+        ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("dt_rank", i32),
     ]
 
 
@@ -104,6 +105,15 @@ class CnnBlock1Args(C.Structure):
     ]
 
 
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32),
+        ("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("bias", fp), ("out", vp), ("ldo", i64), ("x", fp),
+        ("alpha", C.c_float), ("eps1", C.c_float), ("eps2", C.c_float), ("pad_", i32),
+        ("g1", fp), ("b1", fp), ("g2", fp), ("b2", fp), ("stream", vp),
+    ]
+
+
 # every symbol include/conmamba_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("cm_abi_version", C.c_int, []),
@@ -119,6 +129,7 @@ SYMBOLS = [
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
+    ("cm_gemm_bf16", C.c_int, [C.POINTER(GemmArgs)]),
 ]
 
 _lib = None

@@ -33,7 +33,8 @@ template <typename IO, int NS, int TB> struct scan_cl_lds {
     static constexpr int W = 16 / NS;
     static constexpr int kPw = 2 * TB * 64 * 2, kY = 2 * W * TB * 64;
     static constexpr int kRawBytes = 2 * 3 * TB * 64 * (int)sizeof(IO);
-    static constexpr int kBytes = (kPw + kY) * 4 + kRawBytes;
+    static constexpr int kDtFloats = 2 * TB * 16;                 // [2][TB][16] low-rank time-step features
+    static constexpr int kBytes = (kPw + kY) * 4 + kRawBytes + kDtFloats * 4;
 };
 
 // operands of one block's recurrence steps
@@ -53,7 +54,7 @@ constexpr int kLoaderDepth = 3;     // input tiles (of TB steps) the loader wave
 // ---------------------------------------------------------------------------------------------------
 template <typename IO, int TB, bool REV>
 __device__ __forceinline__ void scan_cl_loader(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, unsigned char *raw,
-                                               const bool vec_ok) {
+                                               float *dtl, const bool vec_ok) {
     constexpr int VEC = cm_elem<IO>::kVec;                       // elements per 16-byte vector
     constexpr int CPR = 64 / VEC;                                // 16-byte chunks per 64-channel row
     constexpr int NV = TB * CPR / 64;                            // vectors per lane per tensor per tile (1 or 2)
@@ -68,7 +69,10 @@ __device__ __forceinline__ void scan_cl_loader(const cm_scan_cl_args &p, const c
     const IO *dg = reinterpret_cast<const IO *>(d.delta) + (int64_t)b * d.delta_bs;
     const IO *zg = has_z ? reinterpret_cast<const IO *>(p.z) + (int64_t)b * p.z_bs : nullptr;
 
-    struct Tile { uint4 v[3][NV]; };
+    const bool has_dt = d.dt_low != nullptr;
+    constexpr int NDT = TB * 16 / 64;                            // dt_low values per lane per tile
+    const float *dtg = has_dt ? d.dt_low + (int64_t)b * d.bc_bs : nullptr;
+    struct Tile { uint4 v[3][NV]; float dt[NDT]; };
     auto load_row_vec = [&](const IO *base, int64_t ts, int t, int ch) -> uint4 {
         uint4 r = {0u, 0u, 0u, 0u};
         if (t >= T || ch >= E) return r;
@@ -89,8 +93,16 @@ __device__ __forceinline__ void scan_cl_loader(const cm_scan_cl_args &p, const c
             const int v = lane + 64 * i;
             const int t = tb + v / CPR, ch = c0 + (v % CPR) * VEC;
             tile.v[0][i] = load_row_vec(ug, d.u_ts, t, ch);
-            tile.v[1][i] = load_row_vec(dg, d.delta_ts, t, ch);
+            if (!has_dt) tile.v[1][i] = load_row_vec(dg, d.delta_ts, t, ch);
             if (has_z) tile.v[2][i] = load_row_vec(zg, p.z_ts, t, ch);
+        }
+        if (has_dt) {
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) {
+                const int g = lane + 64 * i;                     // g = r * TB + j
+                const int r = g / TB, j = g % TB;
+                tile.dt[i] = (r < d.dt_rank && tb + j < T) ? dtg[(int64_t)r * d.bc_ns + tb + j] : 0.f;
+            }
         }
     };
     auto commit = [&](int k, const Tile &tile) {                 // registers -> raw[k & 1]
@@ -100,8 +112,16 @@ __device__ __forceinline__ void scan_cl_loader(const cm_scan_cl_args &p, const c
         for (int i = 0; i < NV; ++i) {
             const int v = lane + 64 * i;
             *reinterpret_cast<uint4 *>(dst + 0 * TILE + v * 16) = tile.v[0][i];
-            *reinterpret_cast<uint4 *>(dst + 1 * TILE + v * 16) = tile.v[1][i];
+            if (!has_dt) *reinterpret_cast<uint4 *>(dst + 1 * TILE + v * 16) = tile.v[1][i];
             if (has_z) *reinterpret_cast<uint4 *>(dst + 2 * TILE + v * 16) = tile.v[2][i];
+        }
+        if (has_dt) {
+#pragma unroll
+            for (int i = 0; i < NDT; ++i) {
+                const int g = lane + 64 * i;
+                const int r = g / TB, j = g % TB;
+                dtl[((k & 1) * TB + j) * 16 + r] = tile.dt[i];    // [slot][rank]: one slot's features contiguous
+            }
         }
     };
 
@@ -141,7 +161,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // 4 = no LDS exchange of partial outputs, 5 = per-phase cycle stamps of workgroup 0 / wave 0 into g_stamps
 template <typename IO, int NS, int TB, bool REV, int ABL>
 __device__ __forceinline__ void scan_cl_compute(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, float *lds,
-                                                const unsigned char *raw) {
+                                                const unsigned char *raw, const float *dtl) {
     constexpr int W = 16 / NS;                          // compute waves per workgroup (dstate == 16)
     constexpr int OWN = TB >= W ? TB / W : 1;           // time slots of a block owned by one wave
     constexpr int TILE = TB * 64 * (int)sizeof(IO);
@@ -174,6 +194,10 @@ __device__ __forceinline__ void scan_cl_compute(const cm_scan_cl_args &p, const 
     const float bias = d.delta_bias ? d.delta_bias[cc] : 0.f;
     const float Dv = d.D ? d.D[cc] : 0.f;
     const int nblk = (T + TB - 1) / TB;
+    const bool has_dt = d.dt_low != nullptr;
+    float Wdt[16];                                       // this channel's dt_proj row (zero padded to 16)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wdt[r] = (has_dt && owner && r < d.dt_rank) ? d.dt_weight[(int64_t)cc * d.dt_rank + r] : 0.f;
 
     // owner state: (u, z) of the blocks whose gate is still to be applied, oldest first
     float uq[3][OWN], zq[3][OWN];
@@ -193,8 +217,23 @@ __device__ __forceinline__ void scan_cl_compute(const cm_scan_cl_args &p, const 
             const int slot = wave * OWN + o;
             const int ro = (slot * 64 + lane) * (int)sizeof(IO);
             const float uv = ld_io(reinterpret_cast<const IO *>(rk + 0 * TILE + ro));
-            const float dv = ld_io(reinterpret_cast<const IO *>(rk + 1 * TILE + ro));
             const float zv = has_z ? ld_io(reinterpret_cast<const IO *>(rk + 2 * TILE + ro)) : 0.f;
+            float dv;
+            if (has_dt) {                                // delta = dt_proj.weight[c, :] . dt_low[t, :]   (uniform LDS reads)
+                const float4 *f4 = reinterpret_cast<const float4 *>(dtl + ((k & 1) * TB + slot) * 16);
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 f = f4[q4];
+                    acc0 = fmaf(Wdt[4 * q4 + 0], f.x, acc0);
+                    acc1 = fmaf(Wdt[4 * q4 + 1], f.y, acc1);
+                    acc0 = fmaf(Wdt[4 * q4 + 2], f.z, acc0);
+                    acc1 = fmaf(Wdt[4 * q4 + 3], f.w, acc1);
+                }
+                dv = acc0 + acc1;
+            } else {
+                dv = ld_io(reinterpret_cast<const IO *>(rk + 1 * TILE + ro));
+            }
             float dt = dv + bias;
             if (softplus) dt = cm_softplus(dt);
             dt = tb + slot < T ? dt : 0.f;
@@ -301,14 +340,15 @@ __global__ __launch_bounds__(64 * (16 / NS + 1)) void scan_cl_fwd_kernel(const c
     __shared__ __attribute__((aligned(16))) unsigned char lds[scan_cl_lds<IO, NS, TB>::kBytes];
     float *fl = reinterpret_cast<float *>(lds);
     unsigned char *raw = lds + (scan_cl_lds<IO, NS, TB>::kPw + scan_cl_lds<IO, NS, TB>::kY) * 4;
+    float *dtl = reinterpret_cast<float *>(raw + scan_cl_lds<IO, NS, TB>::kRawBytes);
     const cm_scan_cl_dir &d = p.dir[blockIdx.z];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == W) {                                    // last wave = loader
-        if (d.reverse_time) scan_cl_loader<IO, TB, true>(p, d, raw, vec_ok != 0);
-        else scan_cl_loader<IO, TB, false>(p, d, raw, vec_ok != 0);
+        if (d.reverse_time) scan_cl_loader<IO, TB, true>(p, d, raw, dtl, vec_ok != 0);
+        else scan_cl_loader<IO, TB, false>(p, d, raw, dtl, vec_ok != 0);
     } else {
-        if (d.reverse_time) scan_cl_compute<IO, NS, TB, true, ABL>(p, d, fl, raw);
-        else scan_cl_compute<IO, NS, TB, false, ABL>(p, d, fl, raw);
+        if (d.reverse_time) scan_cl_compute<IO, NS, TB, true, ABL>(p, d, fl, raw, dtl);
+        else scan_cl_compute<IO, NS, TB, false, ABL>(p, d, fl, raw, dtl);
     }
 }
 
@@ -324,8 +364,8 @@ int launch(const cm_scan_cl_args &a) {
     int vec_ok = a.dim % VEC == 0 && (!a.z || (cm_aligned(a.z, 16) && a.z_bs % VEC == 0 && a.z_ts % VEC == 0));
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];
-        vec_ok = vec_ok && cm_aligned(d.u, 16) && cm_aligned(d.delta, 16) && d.u_bs % VEC == 0 && d.u_ts % VEC == 0 &&
-                 d.delta_bs % VEC == 0 && d.delta_ts % VEC == 0;
+        vec_ok = vec_ok && cm_aligned(d.u, 16) && d.u_bs % VEC == 0 && d.u_ts % VEC == 0;
+        if (!d.dt_low) vec_ok = vec_ok && cm_aligned(d.delta, 16) && d.delta_bs % VEC == 0 && d.delta_ts % VEC == 0;
     }
     if constexpr (sizeof(IO) == 2 && NS == 2) {       // ablation builds exist for the bf16 NS=2 kernel only
         switch (g_debug.load()) {
@@ -367,7 +407,9 @@ extern "C" int cm_scan_cl_fwd(const cm_scan_cl_args *args) {
     CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "scan_cl_fwd: batch %d exceeds the grid limit", a.batch);
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];
-        CM_REQUIRE(d.u && d.delta && d.A && d.B && d.C && d.out, CM_EINVAL, "scan_cl_fwd: dir %d has a NULL tensor", i);
+        CM_REQUIRE(d.u && (d.delta || d.dt_low) && d.A && d.B && d.C && d.out, CM_EINVAL, "scan_cl_fwd: dir %d has a NULL tensor", i);
+        CM_REQUIRE(!d.dt_low || (d.dt_weight && d.dt_rank >= 1 && d.dt_rank <= 16), CM_EUNSUPPORTED,
+                   "scan_cl_fwd: in-kernel dt_proj needs dt_weight and 1 <= dt_rank <= 16 (got %d)", d.dt_rank);
     }
     // states per lane: fewest waves that still give >= 2 waves per SIMD (2048 waves), else the finest split
     const long wg = (long)((a.dim + 63) / 64) * a.batch * a.ndir;

@@ -31,7 +31,8 @@ class _LayerCache:
         c = lambda t: t.detach().to(dtype).contiguous()
         f = lambda t: None if t is None else t.detach().float().contiguous()
         ffn = lambda m: dict(ln=(f(m[0].weight), f(m[0].bias), m[0].eps), w1=c(m[1].ffn[0].weight), b1=c(m[1].ffn[0].bias),
-                             w2=c(m[1].ffn[3].weight), b2=c(m[1].ffn[3].bias))
+                             w2=c(m[1].ffn[3].weight), b2=c(m[1].ffn[3].bias), b1f=f(m[1].ffn[0].bias),
+                             b2f=f(m[1].ffn[3].bias))
         self.ffn1, self.ffn2 = ffn(layer.ffn_module1), ffn(layer.ffn_module2)
         self.norm1 = (f(layer.norm1.norm.weight), f(layer.norm1.norm.bias), layer.norm1.norm.eps)
         self.norm2 = (f(layer.norm2.norm.weight), f(layer.norm2.norm.bias), layer.norm2.norm.eps)
@@ -48,11 +49,14 @@ class _LayerCache:
             conv, xp, dtp = getattr(m, "conv1d" + sfx), getattr(m, "x_proj" + sfx), getattr(m, "dt_proj" + sfx)
             A_log = getattr(m, "A_b_log" if sfx else "A_log")
             self.dirs.append(dict(conv_w=f(conv.weight).reshape(m.d_inner, -1), conv_b=f(conv.bias), x_proj=c(xp.weight),
-                                  dt_proj=c(dtp.weight), dt_bias=f(dtp.bias), A=(-torch.exp(A_log.detach().float())).contiguous(),
+                                  dt_proj=c(dtp.weight), dt_proj_f32=c(dtp.weight).float().contiguous(), dt_bias=f(dtp.bias), A=(-torch.exp(A_log.detach().float())).contiguous(),
                                   D=f(getattr(m, "D_b" if sfx else "D"))))
         cm = layer.convolution_module
         self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
         self.pw_w, self.pw_b = c(cm.bottleneck[0].weight.squeeze(-1)), c(cm.bottleneck[0].bias)
+        self.pw_bf, self.lin_bf = f(cm.bottleneck[0].bias), f(cm.after_conv[2].bias)
+        self.in_bias_f = None if m.in_proj.bias is None else f(m.in_proj.bias)
+        self.out_bias_f = None if m.out_proj.bias is None else f(m.out_proj.bias)
         self.dw_w, self.dw_b = f(cm.conv.weight), f(cm.conv.bias)
         self.cm_ln2 = (f(cm.after_conv[0].weight), f(cm.after_conv[0].bias), cm.after_conv[0].eps)
         self.lin_w, self.lin_b = c(cm.after_conv[2].weight), c(cm.after_conv[2].bias)
@@ -109,12 +113,16 @@ def bimamba_fused(c: _LayerCache, h, batch, seqlen):
     u2 = ucat.view(rows, 2 * E)
     for i, d in enumerate(c.dirs):
         u = u2[:, i * E:(i + 1) * E]                                     # (rows, E) column slice
-        xdblT = d["x_proj"] @ u.t()                                      # (R+2N, rows): time contiguous per state
-        delta = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)  # (rows, E), pre-bias
-        bc = ops.alloc_bc(2 * N, batch, seqlen, xz.device)
-        bc.view(2 * N, rows).copy_(xdblT[R:])                            # fp32 B | C rows (state, batch, time)
-        dirs.append(dict(u=ucat[:, :, i * E:(i + 1) * E], delta=delta, A=d["A"], B=bc[:N], C=bc[N:], D=d["D"],
-                         delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i)))
+        xdblT = d["x_proj"] @ u.t()                                      # (R+2N, rows): time contiguous per row
+        bc = ops.alloc_bc(R + 2 * N, batch, seqlen, xz.device)
+        bc.view(R + 2 * N, rows).copy_(xdblT)                            # fp32 dt | B | C rows (feature, batch, time)
+        dd = dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], B=bc[R:R + N], C=bc[R + N:], D=d["D"],
+                  delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
+        if R <= 16:                                                      # dt_proj folded into the scan kernel
+            dd.update(dt_low=bc[:R], dt_weight=d["dt_proj_f32"])
+        else:
+            dd["delta"] = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)   # (rows, E), pre-bias
+        dirs.append(dd)
     ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
     y = ycat.view(rows, 2 * E) @ c.out_cat.t()                           # 0.5*(y_f + y_b) @ W_out^T
     if c.out_bias is not None:
@@ -149,6 +157,59 @@ def layer_forward(layer, x, batch, seqlen, dtype, next_ln=None, final_ln=None):
     return x, None
 
 
+import os
+
+# cm_gemm_bf16 (hand-written MFMA GEMM with fused bias/GELU/residual+LayerNorm epilogues) is correct but, in round 1,
+# 2-3x slower than the vendor library on these shapes (profiles/r01/bench_ops_gemm.log): opt-in until it is tuned.
+USE_NATIVE_GEMM = os.environ.get("CM_NATIVE_GEMM", "0") == "1"
+
+
+def _native_gemms_ok(c: _LayerCache, D: int, dtype) -> bool:
+    """cm_gemm_bf16 covers the layer when d_model == 256 (one workgroup owns whole residual rows) in bf16."""
+    F_ = c.ffn1["w1"].shape[0]
+    return (USE_NATIVE_GEMM and dtype == torch.bfloat16 and D == 256 and F_ % 256 == 0 and F_ % 64 == 0 and (2 * c.d_inner) % 256 == 0
+            and c.gamma is None)
+
+
+def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
+    """ConmambaEncoderLayer with every projection on cm_gemm_bf16: bias/GELU and all four residual + LayerNorm seams
+    are GEMM epilogues.  x: fp32 residual (rows, 256), updated in place; h = LN_ffn1(x) in bf16.
+    Returns the bf16 LayerNorm of the layer output under ``next_ln`` (next layer's first LN) or None."""
+    c = _cache(layer, torch.bfloat16)
+    D, E, R, N = x.shape[-1], c.d_inner, c.dt_rank, c.d_state
+    rows = batch * seqlen
+    g = ops.gemm_bf16
+    u1 = g(h, c.ffn1["w1"], c.ffn1["b1f"], epilogue=1)                                        # Linear + GELU
+    h = g(u1, c.ffn1["w2"], c.ffn1["b2f"], epilogue=2, x=x, alpha=0.5, norm2=c.norm1)        # x += 0.5 ffn1 ; norm1
+    xz = g(h, c.in_proj, c.in_bias_f, epilogue=0)                                            # (rows, 2E) = [x | z]
+    xz3 = xz.view(batch, seqlen, 2 * E)
+    ucat = torch.empty((batch, seqlen, 2 * E), dtype=xz.dtype, device=xz.device)
+    ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                    True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+    ycat = torch.empty_like(ucat)
+    u2d = ucat.view(rows, 2 * E)
+    dirs = []
+    for i, d in enumerate(c.dirs):
+        xdblT = d["x_proj"] @ u2d[:, i * E:(i + 1) * E].t()                                   # (R+2N, rows), library GEMM
+        bc = ops.alloc_bc(R + 2 * N, batch, seqlen, xz.device)
+        bc.view(R + 2 * N, rows).copy_(xdblT)
+        dd = dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], B=bc[R:R + N], C=bc[R + N:], D=d["D"],
+                  delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
+        if R <= 16:
+            dd.update(dt_low=bc[:R], dt_weight=d["dt_proj_f32"])
+        else:
+            dd["delta"] = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)
+        dirs.append(dd)
+    ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
+    h = g(ycat.view(rows, 2 * E), c.out_cat, c.out_bias_f, epilogue=2, x=x, alpha=1.0, norm2=c.cm_ln)   # x += mixer
+    pw = g(h, c.pw_w, c.pw_bf, epilogue=0).view(batch, seqlen, 2 * D)
+    gl = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2])
+    h = g(gl.view(rows, D), c.lin_w, c.lin_bf, epilogue=2, x=x, alpha=1.0, norm2=c.ffn2["ln"])           # x += conv
+    u2 = g(h, c.ffn2["w1"], c.ffn2["b1f"], epilogue=1)
+    return g(u2, c.ffn2["w2"], c.ffn2["b2f"], epilogue=2, x=x, alpha=0.5, norm1=c.norm2, norm2=next_ln,
+             want_out=next_ln is not None)                                                   # x = norm2(x + 0.5 ffn2)
+
+
 @torch.no_grad()
 def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None):
     """ConmambaEncoder.forward (eval, no grad) through the fused path: src (B, T, D) -> (B, T, D) fp32."""
@@ -159,6 +220,13 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None):
         x = src.detach().float().reshape(batch * seqlen, D).contiguous().clone()
         n = len(encoder.layers)
         fin = (encoder.norm.norm.weight.detach().float(), encoder.norm.norm.bias.detach().float(), encoder.norm.norm.eps)
+        caches = [_cache(layer, dtype) for layer in encoder.layers]
+        if all(_native_gemms_ok(c, D, dtype) for c in caches):
+            _, h = ops.add_layernorm(x, None, norm2=caches[0].ffn1["ln"], out_dtype=dtype)      # first LN of layer 0
+            for i, layer in enumerate(encoder.layers):
+                h = layer_forward_native(layer, x, h, batch, seqlen, caches[i + 1].ffn1["ln"] if i + 1 < n else None)
+            _, out = ops.add_layernorm(x, None, norm2=fin, out_dtype=torch.float32)             # encoder's final norm
+            return out.view(batch, seqlen, D)
         out = x
         for i, layer in enumerate(encoder.layers):
             out, _ = layer_forward(layer, x, batch, seqlen, dtype, final_ln=fin if i == n - 1 else None)

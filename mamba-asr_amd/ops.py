@@ -238,24 +238,36 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True):
         a.z, a.z_bs, a.z_ts = _ptr(z), z.stride(0), z.stride(1)
     outs = []
     for i, dd in enumerate(directions):
-        u, delta = dd["u"], dd["delta"]
-        _dev_check(u, delta, dd["A"], dd["B"], dd["C"])
-        _rows_ok(u, "u"), _rows_ok(delta, "delta")
-        if u.dtype != u0.dtype or delta.dtype != u0.dtype or (z is not None and z.dtype != u0.dtype):
+        u, delta = dd["u"], dd.get("delta")
+        dt_low, dt_w = dd.get("dt_low"), dd.get("dt_weight")
+        _dev_check(u, delta, dd["A"], dd["B"], dd["C"], dt_low, dt_w)
+        _rows_ok(u, "u")
+        if delta is not None:
+            _rows_ok(delta, "delta")
+        elif dt_low is None:
+            raise RuntimeError("either delta or (dt_low, dt_weight) is required")
+        if u.dtype != u0.dtype or (delta is not None and delta.dtype != u0.dtype) or (z is not None and z.dtype != u0.dtype):
             raise RuntimeError("u, delta, z must share one dtype")
         Bm, Cm = dd["B"], dd["C"]
         if Bm.dtype != torch.float32 or Bm.stride(2) != 1 or Bm.stride() != Cm.stride() or Bm.shape != (16, b, l):
             raise RuntimeError("B/C must be fp32 (16, batch, seqlen), time-contiguous, with equal strides")
         A, D, bias = _f32c(dd["A"]), _f32c(dd.get("D")), _f32c(dd.get("delta_bias"))
+        dt_w = _f32c(dt_w)
+        if dt_low is not None:
+            if dt_low.dtype != torch.float32 or dt_low.stride(2) != 1 or dt_low.stride()[:2] != Bm.stride()[:2]:
+                raise RuntimeError("dt_low must be fp32 (dt_rank, batch, seqlen) with the strides of B/C")
         out = dd.get("out")
         if out is None:
             out = torch.empty((b, l, d), dtype=u.dtype, device=u.device)
         _rows_ok(out, "out")
-        keep += [A, D, bias]
+        keep += [A, D, bias, dt_w]
         x = a.dir[i]
         x.u, x.delta, x.A, x.B, x.C, x.D, x.delta_bias, x.out = (_ptr(u), _ptr(delta), _ptr(A), _ptr(Bm), _ptr(Cm),
                                                                    _ptr(D), _ptr(bias), _ptr(out))
-        x.u_bs, x.u_ts, x.delta_bs, x.delta_ts = u.stride(0), u.stride(1), delta.stride(0), delta.stride(1)
+        x.dt_low, x.dt_weight, x.dt_rank = _ptr(dt_low), _ptr(dt_w), (0 if dt_low is None else dt_low.shape[0])
+        x.u_bs, x.u_ts = u.stride(0), u.stride(1)
+        if delta is not None:
+            x.delta_bs, x.delta_ts = delta.stride(0), delta.stride(1)
         x.out_bs, x.out_ts = out.stride(0), out.stride(1)
         x.bc_ns, x.bc_bs = Bm.stride(0), Bm.stride(1)
         x.reverse_time = int(bool(dd.get("reverse", False)))
@@ -361,4 +373,37 @@ def cnn_block1(feats, weight, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01, ou
                                                                           float(eps), float(slope), _ptr(out))
     a.stream = _stream()
     _launch("cm_cnn_block1", N.lib().cm_cnn_block1, a, units=b * t)
+    return out
+
+
+def gemm_supported(m: int, n: int, k: int, epilogue: int) -> bool:
+    return k % 64 == 0 and n % 256 == 0 and (epilogue != 2 or n == 256)
+
+
+def gemm_bf16(a, w, bias=None, epilogue=0, x=None, alpha=1.0, norm1=None, norm2=None, want_out=True):
+    """acc = a @ w.T (a (M, K) bf16 row view, w (N, K) bf16) with a fused epilogue (cm_gemm_bf16):
+    0: + bias -> bf16;  1: gelu(+ bias) -> bf16;  2: x += alpha*(acc + bias) [optional LN1 into x], out = LN2(x) bf16.
+    bias / LayerNorm parameters are fp32 tensors; norm = (weight, bias, eps).  Returns out (or None)."""
+    _dev_check(a, w, bias, x)
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or a.stride(1) != 1 or not w.is_contiguous():
+        raise RuntimeError("gemm_bf16: a must be a (M, K) bf16 row-major view and w a contiguous (N, K) bf16 tensor")
+    m, k = a.shape
+    n = w.shape[0]
+    g = N.GemmArgs()
+    g.M, g.N, g.K, g.epilogue = m, n, k, epilogue
+    g.A, g.lda, g.W, g.ldw, g.bias = _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias)
+    out = None
+    if epilogue != 2 or want_out:
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+        g.out, g.ldo = _ptr(out), n
+    if epilogue == 2:
+        if x is None or x.dtype != torch.float32 or not x.is_contiguous() or x.shape != (m, n):
+            raise RuntimeError("gemm_bf16: epilogue 2 needs a contiguous fp32 residual x of shape (M, N)")
+        g.x, g.alpha = _ptr(x), float(alpha)
+        if norm1 is not None:
+            g.g1, g.b1, g.eps1 = _ptr(norm1[0]), _ptr(norm1[1]), float(norm1[2])
+        if norm2 is not None:
+            g.g2, g.b2, g.eps2 = _ptr(norm2[0]), _ptr(norm2[1]), float(norm2[2])
+    g.stream = _stream()
+    _launch("cm_gemm_bf16", N.lib().cm_gemm_bf16, g, units=m)
     return out

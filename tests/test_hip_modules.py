@@ -197,3 +197,24 @@ def test_fused_frontend_and_encoder_match_unfused_and_oracle(dtype):
         close(got, want, rtol=5e-3, atol=1e-3)
     else:
         torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)
+
+
+def test_native_gemm_layer_path_matches_library_path(monkeypatch):
+    """Encoder forward with every projection on cm_gemm_bf16 (fused epilogues) == the library-GEMM fused path."""
+    from mamba_asr_amd import fused
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    torch.manual_seed(3)
+    enc = ConmambaEncoder(num_layers=2, d_model=256, d_ffn=512, kernel_size=31, activation=nn.GELU, bias=True,
+                          dropout=0.0, causal=False, mamba_config=dict(CFG)).to(DEV).eval()
+    for p in enc.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_normal_(p)
+    x = torch.randn(2, 70, 256, device=DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "USE_NATIVE_GEMM", False)
+        ref = fused.encoder_forward(enc, x, dtype=torch.bfloat16)
+        ref32 = fused.encoder_forward(enc, x, dtype=torch.float32)
+        monkeypatch.setattr(fused, "USE_NATIVE_GEMM", True)
+        got = fused.encoder_forward(enc, x, dtype=torch.bfloat16)
+    torch.testing.assert_close(got.cpu(), ref32.cpu(), rtol=3e-2, atol=5e-2)
+    torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)

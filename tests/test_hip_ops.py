@@ -212,3 +212,68 @@ def test_scan_channels_last_two_directions(ops, shape, dtype, split):
     tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
     close(ycat[:, :, :e].float(), refs[0], *tol)
     close(ycat[:, :, e:].float(), refs[1], *tol)
+
+
+@pytest.mark.parametrize("rank", [9, 16])
+def test_scan_channels_last_in_kernel_dt_proj(ops, rank):
+    """delta formed inside cm_scan_cl_fwd from (dt_low, dt_weight) == scan of the explicit delta tensor."""
+    b, l, e = 2, 77, 128
+    gen = torch.Generator().manual_seed(rank)
+    u = torch.randn(b, l, e, generator=gen)
+    z = torch.randn(b, l, e, generator=gen)
+    feat = ops.alloc_bc(rank + 32, b, l, DEV)
+    feat.copy_(torch.randn(rank + 32, b, l, generator=gen))
+    Wdt = torch.randn(e, rank, generator=gen) * 0.3
+    A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
+    D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
+    delta = torch.einsum("er,rbl->ble", Wdt, feat[:rank].cpu())
+    common = dict(u=u.to(DEV), A=A.to(DEV), B=feat[rank:rank + 16], C=feat[rank + 16:], D=D.to(DEV), delta_bias=bias.to(DEV))
+    (ref,) = ops.scan_cl_fwd([dict(common, delta=delta.to(DEV).contiguous())], z=z.to(DEV))
+    (got,) = ops.scan_cl_fwd([dict(common, dt_low=feat[:rank], dt_weight=Wdt.to(DEV))], z=z.to(DEV))
+    close(got, ref, 1e-4, 1e-5)
+    want = O.selective_scan(u.transpose(1, 2), delta.transpose(1, 2), A, feat[rank:rank + 16].cpu().permute(1, 0, 2),
+                            feat[rank + 16:].cpu().permute(1, 0, 2), D, z.transpose(1, 2), bias, True, work_dtype=torch.float64)
+    close(got, want.transpose(1, 2), 2e-4, 5e-5)
+
+
+@pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
+def test_gemm_bf16_epilogues(ops, shape):
+    """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
+    fragment map cannot pass."""
+    m, n, k = shape
+    gen = torch.Generator().manual_seed(m + n)
+    a = (torch.randn(m, k, generator=gen) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=gen) * 0.1).to(torch.bfloat16)
+    bias = torch.randn(n, generator=gen)
+    acc = a.float() @ w.float().t()
+    ga, gw, gb = a.to(DEV), w.to(DEV), bias.to(DEV)
+    out0 = ops.gemm_bf16(ga, gw, gb, epilogue=0)
+    torch.testing.assert_close(out0.float().cpu(), acc + bias, rtol=1.6e-2, atol=2e-2)
+    out0n = ops.gemm_bf16(ga, gw, None, epilogue=0)
+    torch.testing.assert_close(out0n.float().cpu(), acc, rtol=1.6e-2, atol=2e-2)
+    out1 = ops.gemm_bf16(ga, gw, gb, epilogue=1)
+    torch.testing.assert_close(out1.float().cpu(), torch.nn.functional.gelu(acc + bias), rtol=1.6e-2, atol=2e-2)
+    # strided A (column slice of a wider buffer, as [u_fwd | u_bwd])
+    wide = torch.zeros(m, 2 * k, dtype=torch.bfloat16, device=DEV)
+    wide[:, k:] = ga
+    torch.testing.assert_close(ops.gemm_bf16(wide[:, k:], gw, gb, epilogue=0).float().cpu(), out0.float().cpu(), rtol=0, atol=0)
+    if n == 256:
+        x = torch.randn(m, n, generator=gen)
+        g1, b1, g2, b2 = (torch.randn(n, generator=gen) for _ in range(4))
+        r = x + 0.5 * (acc + bias)
+        # residual only
+        gx = x.clone().to(DEV)
+        assert ops.gemm_bf16(ga, gw, gb, epilogue=2, x=gx, alpha=0.5, want_out=False) is None
+        torch.testing.assert_close(gx.cpu(), r, rtol=1e-3, atol=5e-3)
+        # residual + LN2 -> bf16 out, x keeps the un-normalised residual
+        gx = x.clone().to(DEV)
+        out = ops.gemm_bf16(ga, gw, gb, epilogue=2, x=gx, alpha=0.5, norm2=(g2.to(DEV), b2.to(DEV), 1e-5))
+        torch.testing.assert_close(gx.cpu(), r, rtol=1e-3, atol=5e-3)
+        torch.testing.assert_close(out.float().cpu(), torch.nn.functional.layer_norm(r, (n,), g2, b2, 1e-5), rtol=2e-2, atol=3e-2)
+        # LN1 into x, LN2 of that into out
+        gx = x.clone().to(DEV)
+        out = ops.gemm_bf16(ga, gw, gb, epilogue=2, x=gx, alpha=0.5, norm1=(g1.to(DEV), b1.to(DEV), 1e-5),
+                            norm2=(g2.to(DEV), b2.to(DEV), 1e-6))
+        r1 = torch.nn.functional.layer_norm(r, (n,), g1, b1, 1e-5)
+        torch.testing.assert_close(gx.cpu(), r1, rtol=2e-3, atol=1e-2)
+        torch.testing.assert_close(out.float().cpu(), torch.nn.functional.layer_norm(r1, (n,), g2, b2, 1e-6), rtol=2e-2, atol=3e-2)

@@ -86,6 +86,21 @@ def main():
         ms = timeit(lambda: ops.selective_scan_bwd(u, delta, A, B, C, D, z, bias, dout, x, True), iters=5)
         print(f"scan_bwd split={split:2d}: {ms*1e3:8.1f} us")
     lib.cm_scan_set_split(0)
+    if dt == torch.bfloat16:
+        rows = b * l
+        for (n_, k_, epi) in ((1024, 256, 1), (256, 1024, 2), (1024, 256, 0), (512, 256, 0), (256, 256, 2)):
+            a_ = (torch.randn(rows, k_, device=dev, generator=g) * 0.5).to(dt)
+            w_ = (torch.randn(n_, k_, device=dev, generator=g) * 0.05).to(dt)
+            bias_ = torch.randn(n_, device=dev, generator=g)
+            xres = torch.randn(rows, 256, device=dev, generator=g)
+            ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
+            if epi == 2:
+                ms = timeit(lambda: ops.gemm_bf16(a_, w_, bias_, epilogue=2, x=xres, alpha=0.5, norm2=ln))
+            else:
+                ms = timeit(lambda: ops.gemm_bf16(a_, w_, bias_, epilogue=epi))
+            ms_l = timeit(lambda: torch.addmm(bias_.to(dt), a_, w_.t()))
+            fl = 2.0 * rows * n_ * k_
+            print(f"gemm M={rows} N={n_} K={k_} epi={epi}: native {ms*1e3:7.1f} us ({fl/ms/1e9:6.0f} TF/s)   library addmm {ms_l*1e3:7.1f} us ({fl/ms_l/1e9:6.0f} TF/s)")
     w = torch.randn(e, 4, device=dev, generator=g)
     cb = torch.randn(e, device=dev, generator=g)
     ms = timeit(lambda: ops.causal_conv1d_fwd(u, w, cb, True))
