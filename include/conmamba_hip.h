@@ -324,6 +324,48 @@ typedef struct cm_gemm_args {
 
 int cm_gemm_bf16(const cm_gemm_args *args);
 
+/* ---------------------------------------------------------------------------------------
+ * Fbank back end (speechbrain Fbank semantics as used at reference train_CTC.py:285 and configured at
+ * hparams/CTC/conmamba_large.yaml:322-326): STFT (re, im) -> power -> triangular mel filterbank -> 10*log10 with
+ * floor `amin`, plus the per-utterance maximum needed by the top_db clamp.
+ *   spec : (batch, n_freq, frames, 2) fp32  -- torch.stft(..., return_complex=True) viewed as real
+ *   fbank: (n_freq, n_mels) fp32
+ *   db   : (batch, frames, n_mels) fp32  (out)      umax : (batch) fp32, initialised to -inf by the caller (out)
+ * cm_fbank_finish then applies  db = max(db, umax[b] - top_db)  and optionally the global normalisation
+ * (db - mean[m]) / std[m]  (speechbrain InputNormalization, train_CTC.py:287) in place.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_fbank_args {
+    int32_t batch, n_freq, frames, n_mels;
+    const float *spec;
+    const float *fbank;
+    float *db;
+    float *umax;
+    float amin, top_db;
+    const float *mean, *std;     /* (n_mels) or NULL: used by cm_fbank_finish            */
+    void *stream;
+} cm_fbank_args;
+
+int cm_fbank_mel_db(const cm_fbank_args *args);
+int cm_fbank_finish(const cm_fbank_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * SpecAugment masking (speechbrain SpectrogramDrop, reference hparams/CTC/conmamba_large.yaml:273-320 and
+ * train_CTC.py:291): feats[b, t, f] = fill for every (b, t, f) covered by one of the utterance's masks along
+ * `dim` (1 = time, 2 = frequency).  Mask starts/lengths are drawn by the host RNG: int32 (batch, n_masks).
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_spec_drop_args {
+    int32_t batch, frames, n_mels, n_masks;
+    int32_t dim;                 /* 1 = time masks, 2 = frequency masks                   */
+    int32_t pad_;
+    float *feats;                /* (batch, frames, n_mels) fp32, in place                */
+    const int32_t *start;        /* (batch, n_masks)                                      */
+    const int32_t *length;       /* (batch, n_masks)                                      */
+    const float *fill;           /* device scalar: the replacement value (tensor mean)    */
+    void *stream;
+} cm_spec_drop_args;
+
+int cm_spec_drop(const cm_spec_drop_args *args);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,21 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FbankArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
+        ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
+        ("mean", fp), ("std", fp), ("stream", vp),
+    ]
+
+
+class SpecDropArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("frames", i32), ("n_mels", i32), ("n_masks", i32), ("dim", i32), ("pad_", i32),
+        ("feats", fp), ("start", vp), ("length", vp), ("fill", fp), ("stream", vp),
+    ]
+
+
 # every symbol include/conmamba_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("cm_abi_version", C.c_int, []),
@@ -130,6 +145,9 @@ SYMBOLS = [
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
     ("cm_gemm_bf16", C.c_int, [C.POINTER(GemmArgs)]),
+    ("cm_fbank_mel_db", C.c_int, [C.POINTER(FbankArgs)]),
+    ("cm_fbank_finish", C.c_int, [C.POINTER(FbankArgs)]),
+    ("cm_spec_drop", C.c_int, [C.POINTER(SpecDropArgs)]),
 ]
 
 _lib = None

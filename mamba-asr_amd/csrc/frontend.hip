@@ -1,0 +1,123 @@
+// frontend.hip — Fbank back end and SpecAugment masking for gfx950 (contracts in include/conmamba_hip.h).
+// The STFT itself (framing, Hamming window, real FFT) stays on the vendor FFT; everything after it — power,
+// mel projection, dB, per-utterance top_db clamp, global normalisation, masking — is fused here.
+#include "cm_common.h"
+
+namespace {
+
+// one workgroup = one (batch, 16-frame tile); thread = (frame within tile, mel group).
+// power spectrum of the tile is staged in LDS [n_freq][16]; the mel filterbank is sparse (triangles), but a dense
+// 257 x 80 product per frame is only 41 kFLOP: HBM traffic (reading the complex spectrum once) dominates.
+constexpr int FT = 16;
+
+__global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p) {
+    extern __shared__ float pw[];                                 // [n_freq][FT] then [2][n_mels] band limits
+    const int b = blockIdx.y, t0 = blockIdx.x * FT;
+    const int F = p.n_freq, T = p.frames, M = p.n_mels;
+    int *band = reinterpret_cast<int *>(pw + F * FT);             // triangular filters are contiguous bands: [lo, hi)
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        int lo = F, hi = 0;
+        for (int f = 0; f < F; ++f)
+            if (p.fbank[f * M + m] != 0.f) { lo = f < lo ? f : lo; hi = f + 1; }
+        band[m] = lo;
+        band[M + m] = hi;
+    }
+    const float2 *spec = reinterpret_cast<const float2 *>(p.spec) + (int64_t)b * F * T;
+    for (int i = threadIdx.x; i < F * FT; i += blockDim.x) {
+        const int f = i / FT, j = i % FT;                         // consecutive threads -> consecutive frames (contiguous)
+        float v = 0.f;
+        if (t0 + j < T) {
+            const float2 c = spec[(int64_t)f * T + t0 + j];
+            v = c.x * c.x + c.y * c.y;
+        }
+        pw[f * FT + j] = v;
+    }
+    __syncthreads();
+    float local_max = -INFINITY;
+    for (int o = threadIdx.x; o < FT * M; o += blockDim.x) {
+        const int j = o / M, m = o % M;                           // consecutive threads -> consecutive mels (coalesced store)
+        if (t0 + j >= T) continue;
+        float acc = 0.f;
+        for (int f = band[m]; f < band[M + m]; ++f) acc = fmaf(pw[f * FT + j], p.fbank[f * M + m], acc);
+        const float db = 10.f * log10f(fmaxf(acc, p.amin));
+        p.db[((int64_t)b * T + t0 + j) * M + m] = db;
+        local_max = fmaxf(local_max, db);
+    }
+    // per-utterance maximum: wave reduce, one atomic per wave (float max via the int ordering trick)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off, 64));
+    if ((threadIdx.x & 63) == 0 && local_max > -INFINITY) {
+        int *addr = reinterpret_cast<int *>(p.umax + b);
+        if (local_max >= 0.f) atomicMax(addr, __float_as_int(local_max));
+        else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(local_max));
+    }
+}
+
+__global__ __launch_bounds__(256) void fbank_finish_kernel(const cm_fbank_args p) {
+    const int64_t n = (int64_t)p.batch * p.frames * p.n_mels;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % p.n_mels);
+        const int b = (int)(i / ((int64_t)p.frames * p.n_mels));
+        float v = fmaxf(p.db[i], p.umax[b] - p.top_db);
+        if (p.mean) v = (v - p.mean[m]) / p.std[m];
+        p.db[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_drop_kernel(const cm_spec_drop_args p) {
+    const int64_t n = (int64_t)p.batch * p.frames * p.n_mels;
+    const float fill = *p.fill;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % p.n_mels);
+        const int t = (int)((i / p.n_mels) % p.frames);
+        const int b = (int)(i / ((int64_t)p.frames * p.n_mels));
+        const int pos = p.dim == 1 ? t : f;
+        bool hit = false;
+        for (int k = 0; k < p.n_masks; ++k) {
+            const int s = p.start[b * p.n_masks + k], l = p.length[b * p.n_masks + k];
+            hit = hit || (pos >= s && pos < s + l);
+        }
+        if (hit) p.feats[i] = fill;
+    }
+}
+
+}  // namespace
+
+extern "C" int cm_fbank_mel_db(const cm_fbank_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "fbank_mel_db: args is NULL");
+    const cm_fbank_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.n_freq > 0 && a.frames > 0 && a.n_mels > 0 && a.spec && a.fbank && a.db && a.umax, CM_EINVAL,
+               "fbank_mel_db: bad sizes or NULL tensor");
+    const size_t smem = (size_t)a.n_freq * FT * 4 + (size_t)2 * a.n_mels * 4;
+    CM_REQUIRE(a.batch <= 65535 && smem <= 64 * 1024, CM_EUNSUPPORTED, "fbank_mel_db: n_freq %d too large", a.n_freq);
+    dim3 grid((a.frames + FT - 1) / FT, a.batch);
+    hipLaunchKernelGGL(fbank_mel_db_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_fbank_mel_db");
+}
+
+extern "C" int cm_fbank_finish(const cm_fbank_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "fbank_finish: args is NULL");
+    const cm_fbank_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.frames > 0 && a.n_mels > 0 && a.db && a.umax, CM_EINVAL, "fbank_finish: bad sizes or NULL tensor");
+    CM_REQUIRE(!a.mean || a.std, CM_EINVAL, "fbank_finish: mean without std");
+    const int64_t n = (int64_t)a.batch * a.frames * a.n_mels;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fbank_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_fbank_finish");
+}
+
+extern "C" int cm_spec_drop(const cm_spec_drop_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "spec_drop: args is NULL");
+    const cm_spec_drop_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.frames > 0 && a.n_mels > 0 && a.n_masks >= 0 && a.feats && a.fill, CM_EINVAL,
+               "spec_drop: bad sizes or NULL tensor");
+    CM_REQUIRE(a.n_masks == 0 || (a.start && a.length), CM_EINVAL, "spec_drop: masks requested without start/length");
+    CM_REQUIRE(a.dim == 1 || a.dim == 2, CM_EINVAL, "spec_drop: dim must be 1 (time) or 2 (frequency)");
+    if (a.n_masks == 0) return CM_OK;
+    const int64_t n = (int64_t)a.batch * a.frames * a.n_mels;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(spec_drop_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_spec_drop");
+}

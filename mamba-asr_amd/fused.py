@@ -261,7 +261,8 @@ def asr_encode(model, wavs, wav_lens, dtype: Optional[torch.dtype] = None):
     if dtype is None:
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
     with torch.autocast("cuda", enabled=False):
-        feats = model.normalize(model.compute_features(wavs), wav_lens)            # (B, T, n_mels) fp32
+        # Fbank back end + frozen global normalisation in the native kernels (cm_fbank_mel_db / cm_fbank_finish)
+        feats = model.compute_features(wavs, norm=(model.normalize.glob_mean, model.normalize.glob_std))
         c = _frontend_cache(model, dtype)
         b0 = model.CNN.blocks[0]
         y1 = ops.cnn_block1(feats, b0.conv.weight, b0.conv.bias, b0.norm.norm.weight, b0.norm.norm.bias,

@@ -407,3 +407,42 @@ def gemm_bf16(a, w, bias=None, epilogue=0, x=None, alpha=1.0, norm1=None, norm2=
     g.stream = _stream()
     _launch("cm_gemm_bf16", N.lib().cm_gemm_bf16, g, units=m)
     return out
+
+
+def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
+    """torch.stft(..., return_complex=True) output (batch, n_freq, frames) -> (batch, frames, n_mels) fp32 log-mel
+    features with the per-utterance top_db clamp and optional global normalisation (cm_fbank_mel_db + cm_fbank_finish)."""
+    _dev_check(spec, fbank, mean, std)
+    sr = torch.view_as_real(spec) if spec.is_complex() else spec
+    sr = sr.float().contiguous()
+    b, nf, t, _ = sr.shape
+    fb = _f32c(fbank)
+    m = fb.shape[1]
+    db = torch.empty((b, t, m), dtype=torch.float32, device=sr.device)
+    umax = torch.full((b,), float("-inf"), dtype=torch.float32, device=sr.device)
+    a = N.FbankArgs()
+    a.batch, a.n_freq, a.frames, a.n_mels = b, nf, t, m
+    a.spec, a.fbank, a.db, a.umax, a.amin, a.top_db = _ptr(sr), _ptr(fb), _ptr(db), _ptr(umax), float(amin), float(top_db)
+    mean, std = _f32c(mean), _f32c(std)
+    a.mean, a.std = _ptr(mean), _ptr(std)
+    a.stream = _stream()
+    _launch("cm_fbank_mel_db", N.lib().cm_fbank_mel_db, a, units=b * t)
+    _launch("cm_fbank_finish", N.lib().cm_fbank_finish, a, units=b * t)
+    return db
+
+
+def spec_drop_(feats, start, length, dim, fill):
+    """In-place SpecAugment masking (cm_spec_drop): feats (batch, frames, n_mels) fp32; start/length int32
+    (batch, n_masks); dim 1 = time, 2 = frequency; fill = 0-dim device tensor."""
+    _dev_check(feats, start, length, fill)
+    if feats.dtype != torch.float32 or not feats.is_contiguous():
+        raise RuntimeError("spec_drop_: feats must be contiguous fp32")
+    start, length = start.to(torch.int32).contiguous(), length.to(torch.int32).contiguous()
+    fill = fill.reshape(1).float()
+    b, t, m = feats.shape
+    a = N.SpecDropArgs()
+    a.batch, a.frames, a.n_mels, a.n_masks, a.dim = b, t, m, start.shape[1], dim
+    a.feats, a.start, a.length, a.fill = _ptr(feats), _ptr(start), _ptr(length), _ptr(fill)
+    a.stream = _stream()
+    _launch("cm_spec_drop", N.lib().cm_spec_drop, a, units=b * t)
+    return feats

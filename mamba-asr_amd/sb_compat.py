@@ -116,10 +116,15 @@ class Fbank(nn.Module):
         self.register_buffer("fbank", mel_filterbank(n_mels, n_fft, sample_rate, f_min, f_max), persistent=False)
 
     @torch.no_grad()
-    def forward(self, wav):
+    def forward(self, wav, norm=None):
+        """``norm`` = (mean, std) folds the global normalisation into the native back end (GPU only)."""
         with torch.autocast(device_type=wav.device.type, enabled=False):          # speechbrain forces fp32 here
             spec = torch.stft(wav.float(), self.n_fft, self.hop, self.win, self.window, center=True,
                               pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+            if wav.is_cuda:                                                        # native back end (cm_fbank_*)
+                from . import ops
+                mean, std = norm if norm is not None else (None, None)
+                return ops.fbank_from_stft(spec, self.fbank, self.amin, self.top_db, mean, std)
             power = (spec.real ** 2 + spec.imag ** 2).transpose(1, 2)
             mel = power @ self.fbank
             db = 10.0 * torch.log10(torch.clamp(mel, min=self.amin))
@@ -179,8 +184,11 @@ class SpectrogramDrop(nn.Module):
         ar = torch.arange(size, device=spec.device).view(1, 1, -1)
         mask = ((ar >= start[..., None]) & (ar < (start + length)[..., None])).any(1)       # (b, size)
         mask = mask[:, :, None] if self.dim == 1 else mask[:, None, :]
-        val = spec.mean() if self.replace == "mean" else 0.0
-        return spec.masked_fill(mask, float(val) if not torch.is_tensor(val) else val.item())
+        val = spec.mean() if self.replace == "mean" else torch.zeros((), device=spec.device)
+        if spec.is_cuda and spec.dtype == torch.float32:                           # native masking kernel (cm_spec_drop)
+            from . import ops
+            return ops.spec_drop_(spec.contiguous().clone(), start, length, self.dim, val)
+        return torch.where(mask, val.to(spec.dtype), spec)
 
 
 class Augmenter(nn.Module):
