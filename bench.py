@@ -143,8 +143,19 @@ def main():
             units = scans[0][1]                                      # scan steps (batch * T * directions) per launch
             alg_bytes = units * (4 * e_inner + 2 * n_state) * s      # (4E+2N)*s per scan step per direction
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM traffic of one launch from the PMC passes (FETCH_SIZE, WRITE_SIZE collected separately with rocprofv3
+            # --pmc on tools/pmc_scan.py, profiles/): valid for the configuration it was measured on only
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01", "pmc_scan.json")) as f:
+                    pmc = json.load(f)
+                w = pmc["workload"]
+                if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (a.batch, a.frames // 4, e_inner, "bf16" if amp is not None else "f32"):
+                    traffic = pmc["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": "scan_cl_fwd_kernel (cm_scan_cl_fwd: both BiMamba directions per launch)", "avg_launch_us": round(avg_ms * 1e3, 1),
                     "launches_per_step": len(scans) // 3, "alg_bytes_per_launch": alg_bytes}
 
