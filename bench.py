@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="conmamba_large_ctc")
-    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU (SURVEY §8d config 3: 16 x 40 s)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="utterances per GPU (40 s each).  The reference recipe fills 45-80 GB GPUs with 850-1700 s of audio "
+                         "per batch (hparams/CTC/conmamba_large.yaml:108-113); 32 x 40 s = 1280 s on a 288 GB MI355X. "
+                         "SURVEY §8d's 16 x 40 s: --batch 16")
     ap.add_argument("--frames", type=int, default=4000, help="10 ms audio frames per utterance (L)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

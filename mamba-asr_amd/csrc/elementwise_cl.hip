@@ -274,6 +274,7 @@ template <typename OT, int MAXPT>
 __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_args p, int T1, int F1) {
     __shared__ float rows[3][128 + 2];                 // input rows 2*t1-1 .. 2*t1+1 with reflect padding in F (F <= 128)
     __shared__ float red[2][4];
+    __shared__ float wsh[128 * 9 + 128];               // conv taps [C][9] and bias [C] (C <= 128)
     const int C = p.C, F = p.F, T = p.T;
     const int P = p.pad_out;
     const int tp = blockIdx.x, b = blockIdx.y;
@@ -284,6 +285,8 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
         const int tin = reflect_idx(2 * t1 + r - 1, T), fin = reflect_idx(f - 1, F);
         rows[r][f] = feats[(int64_t)tin * F + fin];
     }
+    for (int i = threadIdx.x; i < C * 9; i += blockDim.x) wsh[i] = p.weight[i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) wsh[C * 9 + i] = p.bias ? p.bias[i] : 0.f;
     __syncthreads();
     const int n = F1 * C;
     float v[MAXPT];
@@ -294,11 +297,11 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
         v[i] = 0.f;
         if (o < n) {
             const int f1 = o / C, c = o % C;
-            float acc = p.bias ? p.bias[c] : 0.f;
+            float acc = wsh[C * 9 + c];
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-                for (int df = 0; df < 3; ++df) acc = fmaf(p.weight[c * 9 + dt * 3 + df], rows[dt][2 * f1 + df], acc);
+                for (int df = 0; df < 3; ++df) acc = fmaf(wsh[c * 9 + dt * 3 + df], rows[dt][2 * f1 + df], acc);
             v[i] = acc;
             s += acc;
         }
@@ -341,7 +344,7 @@ extern "C" int cm_cnn_block1(const cm_cnn_block1_args *args) {
     const cm_cnn_block1_args &a = *args;
     CM_REQUIRE(a.batch > 0 && a.T > 1 && a.F > 1 && a.C > 0 && a.feats && a.weight && a.ln_g && a.ln_b && a.out, CM_EINVAL,
                "cnn_block1: bad sizes or NULL tensor");
-    CM_REQUIRE(a.F <= 128, CM_EUNSUPPORTED, "cnn_block1: F %d unsupported (<= 128)", a.F);
+    CM_REQUIRE(a.F <= 128 && a.C <= 128, CM_EUNSUPPORTED, "cnn_block1: F %d / C %d unsupported (<= 128)", a.F, a.C);
     CM_REQUIRE(a.pad_out == 0 || a.pad_out == 1, CM_EINVAL, "cnn_block1: pad_out must be 0 or 1");
     const int T1 = (a.T + 1) / 2, F1 = (a.F + 1) / 2;
     CM_REQUIRE(F1 * a.C <= 16 * 256 && T1 >= 3 && F1 >= 3, CM_EUNSUPPORTED, "cnn_block1: F1*C = %d unsupported (<= 4096)", F1 * a.C);

@@ -52,6 +52,12 @@ class _LayerCache:
                                   dt_proj=c(dtp.weight), dt_proj_f32=c(dtp.weight).float().contiguous(), dt_bias=f(dtp.bias), A=(-torch.exp(A_log.detach().float())).contiguous(),
                                   D=f(getattr(m, "D_b" if sfx else "D"))))
         cm = layer.convolution_module
+        # both directions' x_proj as ONE GEMM over [u_fwd | u_bwd]: block-diagonal (2*(R+2N), 2E) weight
+        P = self.dt_rank + 2 * self.d_state
+        xbd = torch.zeros(2 * P, 2 * m.d_inner, dtype=dtype, device=m.x_proj.weight.device)
+        xbd[:P, :m.d_inner] = m.x_proj.weight.detach().to(dtype)
+        xbd[P:, m.d_inner:] = m.x_proj_b.weight.detach().to(dtype)
+        self.x_proj_bd = xbd
         self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
         self.pw_w, self.pw_b = c(cm.bottleneck[0].weight.squeeze(-1)), c(cm.bottleneck[0].bias)
         self.pw_bf, self.lin_bf = f(cm.bottleneck[0].bias), f(cm.after_conv[2].bias)
@@ -97,6 +103,27 @@ def _ffn(x, y_in, p, dtype):
     return torch.addmm(p["b2"], h, p["w2"].t())
 
 
+def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen):
+    """x_proj for both directions (one library GEMM, time-contiguous output rows), fp32 feature buffer, and the two
+    direction descriptors of cm_scan_cl_fwd."""
+    E, R, N = c.d_inner, c.dt_rank, c.d_state
+    rows, P = batch * seqlen, c.dt_rank + 2 * c.d_state
+    xdblT = c.x_proj_bd @ ucat.view(rows, 2 * E).t()                      # (2P, rows): [dt | B | C] fwd, then bwd
+    feat = ops.alloc_bc(2 * P, batch, seqlen, ucat.device)
+    feat.view(2 * P, rows).copy_(xdblT)                                   # one bf16 -> fp32 conversion
+    dirs = []
+    for i, d in enumerate(c.dirs):
+        f = feat[i * P:(i + 1) * P]
+        dd = dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], B=f[R:R + N], C=f[R + N:], D=d["D"],
+                  delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
+        if R <= 16:                                                       # dt_proj folded into the scan kernel
+            dd.update(dt_low=f[:R], dt_weight=d["dt_proj_f32"])
+        else:
+            dd["delta"] = (xdblT[i * P:i * P + R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)   # (rows, E), pre-bias
+        dirs.append(dd)
+    return dirs
+
+
 def bimamba_fused(c: _LayerCache, h, batch, seqlen):
     """h: LN'd input (rows, D) in the compute dtype -> mixer output (rows, D) (reference bimamba.py:192-253)."""
     E, R, N = c.d_inner, c.dt_rank, c.d_state
@@ -109,20 +136,7 @@ def bimamba_fused(c: _LayerCache, h, batch, seqlen):
     ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
                     True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
     ycat = torch.empty_like(ucat)
-    dirs = []
-    u2 = ucat.view(rows, 2 * E)
-    for i, d in enumerate(c.dirs):
-        u = u2[:, i * E:(i + 1) * E]                                     # (rows, E) column slice
-        xdblT = d["x_proj"] @ u.t()                                      # (R+2N, rows): time contiguous per row
-        bc = ops.alloc_bc(R + 2 * N, batch, seqlen, xz.device)
-        bc.view(R + 2 * N, rows).copy_(xdblT)                            # fp32 dt | B | C rows (feature, batch, time)
-        dd = dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], B=bc[R:R + N], C=bc[R + N:], D=d["D"],
-                  delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
-        if R <= 16:                                                      # dt_proj folded into the scan kernel
-            dd.update(dt_low=bc[:R], dt_weight=d["dt_proj_f32"])
-        else:
-            dd["delta"] = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)   # (rows, E), pre-bias
-        dirs.append(dd)
+    dirs = _scan_dirs(c, ucat, ycat, batch, seqlen)
     ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
     y = ycat.view(rows, 2 * E) @ c.out_cat.t()                           # 0.5*(y_f + y_b) @ W_out^T
     if c.out_bias is not None:
@@ -187,19 +201,7 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
     ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
                     True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
     ycat = torch.empty_like(ucat)
-    u2d = ucat.view(rows, 2 * E)
-    dirs = []
-    for i, d in enumerate(c.dirs):
-        xdblT = d["x_proj"] @ u2d[:, i * E:(i + 1) * E].t()                                   # (R+2N, rows), library GEMM
-        bc = ops.alloc_bc(R + 2 * N, batch, seqlen, xz.device)
-        bc.view(R + 2 * N, rows).copy_(xdblT)
-        dd = dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], B=bc[R:R + N], C=bc[R + N:], D=d["D"],
-                  delta_bias=d["dt_bias"], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
-        if R <= 16:
-            dd.update(dt_low=bc[:R], dt_weight=d["dt_proj_f32"])
-        else:
-            dd["delta"] = (xdblT[:R].t() @ d["dt_proj"].t()).view(batch, seqlen, E)
-        dirs.append(dd)
+    dirs = _scan_dirs(c, ucat, ycat, batch, seqlen)
     ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
     h = g(ycat.view(rows, 2 * E), c.out_cat, c.out_bias_f, epilogue=2, x=x, alpha=1.0, norm2=c.cm_ln)   # x += mixer
     pw = g(h, c.pw_w, c.pw_bf, epilogue=0).view(batch, seqlen, 2 * D)
