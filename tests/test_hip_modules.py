@@ -218,3 +218,31 @@ def test_native_gemm_layer_path_matches_library_path(monkeypatch):
         got = fused.encoder_forward(enc, x, dtype=torch.bfloat16)
     torch.testing.assert_close(got.cpu(), ref32.cpu(), rtol=3e-2, atol=5e-2)
     torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)
+
+
+def test_ctc_loss_matches_oracle_within_1e3():
+    """North-star parity figure: CTC loss of the full path (wav -> Fbank -> CNN -> ConMamba encoder -> ctc_lin ->
+    log-softmax -> CTC) on the GPU vs the CPU oracle, fp32: |delta| <= 1e-3; bf16 autocast delta is reported."""
+    from mamba_asr_amd.asr import ASRConfig, ConMambaASR, synthetic_wavs, samples_for_frames
+    from oracle import conmamba_oracle as O
+    cfg = ASRConfig("tiny", d_model=64, d_ffn=128, num_encoder_layers=3, n_fft=400, seed=11)
+    model = ConMambaASR(cfg).to(DEV).eval()
+    wavs, lens = synthetic_wavs(3, samples_for_frames(400), 21, DEV)
+    gen = torch.Generator().manual_seed(4)
+    tokens = torch.randint(3, 31, (3, 20), generator=gen)
+    tok_lens = torch.tensor([1.0, 0.8, 0.6])
+    with torch.no_grad():
+        model.features(wavs, lens)                                         # normaliser statistics from the first batch
+        p32 = model.forward_ctc(wavs, lens)
+        loss32 = model.ctc_objective(p32, tokens.to(DEV), lens, tok_lens.to(DEV))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pbf = model.forward_ctc(wavs, lens)
+        lossbf = model.ctc_objective(pbf.float(), tokens.to(DEV), lens, tok_lens.to(DEV))
+    p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    enc = O.asr_encode(p, wavs.cpu(), lens.cpu(), 3, p["normalize.glob_mean"], p["normalize.glob_std"], n_fft=400)
+    logp = torch.log_softmax(torch.nn.functional.linear(enc, p["ctc_lin.w.weight"], p["ctc_lin.w.bias"]), -1)
+    ref = O.ctc_loss_batchmean(logp, tokens, lens.cpu(), tok_lens)
+    d32, dbf = abs(float(loss32) - float(ref)), abs(float(lossbf) - float(ref))
+    print(f"CTC loss: oracle {float(ref):.5f}  gpu fp32 {float(loss32):.5f} (|delta| {d32:.2e})  gpu bf16 {float(lossbf):.5f} (|delta| {dbf:.2e})")
+    assert d32 <= 1e-3
+    assert dbf <= 5e-2 * max(1.0, abs(float(ref)))
