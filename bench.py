@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="utterances in the CPU-baseline sample")
     return ap.parse_args()
 
 

@@ -342,6 +342,7 @@ typedef struct cm_fbank_args {
     float *umax;
     float amin, top_db;
     const float *mean, *std;     /* (n_mels) or NULL: used by cm_fbank_finish            */
+    const int32_t *band_lo, *band_hi;   /* optional (n_mels): filter m is non-zero only on bins [lo, hi) */
     void *stream;
 } cm_fbank_args;
 

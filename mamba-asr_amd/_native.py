@@ -118,7 +118,7 @@ class FbankArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
         ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
-        ("mean", fp), ("std", fp), ("stream", vp),
+        ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("stream", vp),
     ]
 
 

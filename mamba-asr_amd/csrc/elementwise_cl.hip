@@ -291,19 +291,25 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
     const int n = F1 * C;
     float v[MAXPT];
     float s = 0.f, sq = 0.f;
+    // thread owns channel PAIRS: o = 2*tid + 512*i -> (f1, c, c+1); C is even, so a pair never straddles f1
 #pragma unroll
-    for (int i = 0; i < MAXPT; ++i) {
-        const int o = threadIdx.x + i * 256;           // o = f1 * C + c  (channel fastest: coalesced stores)
-        v[i] = 0.f;
+    for (int i = 0; i < MAXPT / 2; ++i) {
+        const int o = 2 * threadIdx.x + i * 512;
+        v[2 * i] = v[2 * i + 1] = 0.f;
         if (o < n) {
             const int f1 = o / C, c = o % C;
-            float acc = wsh[C * 9 + c];
+            float a0 = wsh[C * 9 + c], a1 = wsh[C * 9 + c + 1];
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-                for (int df = 0; df < 3; ++df) acc = fmaf(wsh[c * 9 + dt * 3 + df], rows[dt][2 * f1 + df], acc);
-            v[i] = acc;
-            s += acc;
+                for (int df = 0; df < 3; ++df) {
+                    const float xin = rows[dt][2 * f1 + df];
+                    a0 = fmaf(wsh[c * 9 + dt * 3 + df], xin, a0);
+                    a1 = fmaf(wsh[(c + 1) * 9 + dt * 3 + df], xin, a1);
+                }
+            v[2 * i] = a0;
+            v[2 * i + 1] = a1;
+            s += a0 + a1;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,26 +318,38 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
     __syncthreads();
     const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
 #pragma unroll
-    for (int i = 0; i < MAXPT; ++i) {
-        const int o = threadIdx.x + i * 256;
-        if (o < n) { const float d = v[i] - mean; sq += d * d; }
+    for (int i = 0; i < MAXPT / 2; ++i) {
+        const int o = 2 * threadIdx.x + i * 512;
+        if (o < n) {
+            const float d0 = v[2 * i] - mean, d1 = v[2 * i + 1] - mean;
+            sq += d0 * d0 + d1 * d1;
+        }
     }
     sq = wave_sum(sq);
     if (lane == 0) red[1][wave] = sq;
     __syncthreads();
     const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n + p.eps);
     OT *out = reinterpret_cast<OT *>(p.out) + ((int64_t)b * (T1 + 2 * P) + tp) * (F1 + 2 * P) * C;
+    auto store2 = [&](OT *dst, float y0, float y1) {
+        if constexpr (sizeof(OT) == 2) {
+            *reinterpret_cast<uint32_t *>(dst) = (uint32_t)cm_elem<OT>::to_bits(y0) | ((uint32_t)cm_elem<OT>::to_bits(y1) << 16);
+        } else {
+            *reinterpret_cast<float2 *>(dst) = make_float2(y0, y1);
+        }
+    };
 #pragma unroll
-    for (int i = 0; i < MAXPT; ++i) {
-        const int o = threadIdx.x + i * 256;
+    for (int i = 0; i < MAXPT / 2; ++i) {
+        const int o = 2 * threadIdx.x + i * 512;
         if (o < n) {
             const int f1 = o / C, c = o % C;
-            float y = (v[i] - mean) * rstd * p.ln_g[o] + p.ln_b[o];
-            y = y > 0.f ? y : p.slope * y;
-            cm_elem<OT>::store(out + (f1 + P) * C + c, y);
+            float y0 = (v[2 * i] - mean) * rstd * p.ln_g[o] + p.ln_b[o];
+            float y1 = (v[2 * i + 1] - mean) * rstd * p.ln_g[o + 1] + p.ln_b[o + 1];
+            y0 = y0 > 0.f ? y0 : p.slope * y0;
+            y1 = y1 > 0.f ? y1 : p.slope * y1;
+            store2(out + (f1 + P) * C + c, y0, y1);
             if (P) {                                   // reflected frequency border: fp = 0 <- f1 = 1, fp = F1+1 <- f1 = F1-2
-                if (f1 == 1) cm_elem<OT>::store(out + c, y);
-                if (f1 == F1 - 2) cm_elem<OT>::store(out + (F1 + 1) * C + c, y);
+                if (f1 == 1) store2(out + c, y0, y1);
+                if (f1 == F1 - 2) store2(out + (F1 + 1) * C + c, y0, y1);
             }
         }
     }
@@ -344,7 +362,7 @@ extern "C" int cm_cnn_block1(const cm_cnn_block1_args *args) {
     const cm_cnn_block1_args &a = *args;
     CM_REQUIRE(a.batch > 0 && a.T > 1 && a.F > 1 && a.C > 0 && a.feats && a.weight && a.ln_g && a.ln_b && a.out, CM_EINVAL,
                "cnn_block1: bad sizes or NULL tensor");
-    CM_REQUIRE(a.F <= 128 && a.C <= 128, CM_EUNSUPPORTED, "cnn_block1: F %d / C %d unsupported (<= 128)", a.F, a.C);
+    CM_REQUIRE(a.F <= 128 && a.C <= 128 && a.C % 2 == 0, CM_EUNSUPPORTED, "cnn_block1: F %d / C %d unsupported (<= 128, C even)", a.F, a.C);
     CM_REQUIRE(a.pad_out == 0 || a.pad_out == 1, CM_EINVAL, "cnn_block1: pad_out must be 0 or 1");
     const int T1 = (a.T + 1) / 2, F1 = (a.F + 1) / 2;
     CM_REQUIRE(F1 * a.C <= 16 * 256 && T1 >= 3 && F1 >= 3, CM_EUNSUPPORTED, "cnn_block1: F1*C = %d unsupported (<= 4096)", F1 * a.C);

@@ -15,12 +15,9 @@ __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p
     const int b = blockIdx.y, t0 = blockIdx.x * FT;
     const int F = p.n_freq, T = p.frames, M = p.n_mels;
     int *band = reinterpret_cast<int *>(pw + F * FT);             // triangular filters are contiguous bands: [lo, hi)
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        int lo = F, hi = 0;
-        for (int f = 0; f < F; ++f)
-            if (p.fbank[f * M + m] != 0.f) { lo = f < lo ? f : lo; hi = f + 1; }
-        band[m] = lo;
-        band[M + m] = hi;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {           // triangular filters: contiguous bands (host-provided)
+        band[m] = p.band_lo ? p.band_lo[m] : 0;
+        band[M + m] = p.band_hi ? p.band_hi[m] : F;
     }
     const float2 *spec = reinterpret_cast<const float2 *>(p.spec) + (int64_t)b * F * T;
     for (int i = threadIdx.x; i < F * FT; i += blockDim.x) {

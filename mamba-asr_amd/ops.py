@@ -409,6 +409,22 @@ def gemm_bf16(a, w, bias=None, epilogue=0, x=None, alpha=1.0, norm1=None, norm2=
     return out
 
 
+_BANDS = {}
+
+
+def _mel_bands(fb: torch.Tensor):
+    """Per-filter [lo, hi) range of non-zero bins (triangular filters are contiguous), cached per filterbank tensor."""
+    key = (fb.data_ptr(), tuple(fb.shape))
+    if key not in _BANDS:
+        nz = (fb != 0)
+        idx = torch.arange(fb.shape[0], device=fb.device)[:, None]
+        lo = torch.where(nz, idx, fb.shape[0]).amin(0).to(torch.int32)
+        hi = (torch.where(nz, idx, -1).amax(0) + 1).to(torch.int32)
+        lo = torch.minimum(lo, hi)
+        _BANDS[key] = (lo.contiguous(), hi.contiguous())
+    return _BANDS[key]
+
+
 def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     """torch.stft(..., return_complex=True) output (batch, n_freq, frames) -> (batch, frames, n_mels) fp32 log-mel
     features with the per-utterance top_db clamp and optional global normalisation (cm_fbank_mel_db + cm_fbank_finish)."""
@@ -425,6 +441,8 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     a.spec, a.fbank, a.db, a.umax, a.amin, a.top_db = _ptr(sr), _ptr(fb), _ptr(db), _ptr(umax), float(amin), float(top_db)
     mean, std = _f32c(mean), _f32c(std)
     a.mean, a.std = _ptr(mean), _ptr(std)
+    lo, hi = _mel_bands(fb)
+    a.band_lo, a.band_hi = _ptr(lo), _ptr(hi)
     a.stream = _stream()
     _launch("cm_fbank_mel_db", N.lib().cm_fbank_mel_db, a, units=b * t)
     _launch("cm_fbank_finish", N.lib().cm_fbank_finish, a, units=b * t)
