@@ -86,7 +86,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
     from mamba_asr_amd import ops
@@ -111,7 +112,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -123,9 +124,9 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # MAX over ranks
         elapsed = float(t.item())
     assert torch.isfinite(out.float()).all()
     frames_total = world * a.batch * a.frames * a.steps
@@ -184,7 +185,7 @@ def main():
             "roofline": roof, "cpu_baseline": base,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
