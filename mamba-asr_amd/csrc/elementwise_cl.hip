@@ -31,10 +31,12 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // ------------------------------------------------------------------------------------------------
 template <typename IO, int W, int TC>
 __global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, int vpr) {
-    constexpr int N = cm_elem<IO>::kVec;
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;          // flat (chunk, vector) index
+    // one thread = one 32-bit word of channels (2 x bf16 or 1 x fp32) x TC consecutive steps: ~80 VGPRs, so 6+ waves
+    // per SIMD stay resident (the 8-channel/16-byte version needed 192 VGPRs and ran at 2 waves per SIMD)
+    constexpr int N = 4 / (int)sizeof(IO);
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nchunk = (p.seqlen + TC - 1) / TC;
-    const int vec = v % vpr, chunk = (v / vpr) % nchunk, b = v / (vpr * nchunk);
+    const int vec = (int)(v % vpr), chunk = (int)((v / vpr) % nchunk), b = (int)(v / ((int64_t)vpr * nchunk));
     if (b >= p.batch) return;
     const int c0 = vec * N;
     const bool two = p.y_bwd != nullptr;
@@ -42,12 +44,11 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, i
     IO *yf = reinterpret_cast<IO *>(p.y_fwd) + (int64_t)b * p.yf_bs + c0;
     IO *yb = two ? reinterpret_cast<IO *>(p.y_bwd) + (int64_t)b * p.yb_bs + c0 : nullptr;
     const int t0 = chunk * TC;
-    // rows t0-(W-1) .. t0+TC-1+(W-1): every load is issued before the first use
-    uint4 raw[TC + 2 * (W - 1)];
+    uint32_t raw[TC + 2 * (W - 1)];                               // rows t0-(W-1) .. t0+TC-1+(W-1), all loads issued first
 #pragma unroll
     for (int r = 0; r < TC + 2 * (W - 1); ++r) {
         const int s = t0 - (W - 1) + r;
-        raw[r] = (s >= 0 && s < p.seqlen) ? *reinterpret_cast<const uint4 *>(x + (int64_t)s * p.x_ts) : make_uint4(0u, 0u, 0u, 0u);
+        raw[r] = (s >= 0 && s < p.seqlen) ? *reinterpret_cast<const uint32_t *>(x + (int64_t)s * p.x_ts) : 0u;
     }
     float wf[N][W], wb[N][W], bf[N], bb[N];
 #pragma unroll
@@ -60,10 +61,13 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, i
         bf[j] = p.bias_f ? p.bias_f[c0 + j] : 0.f;
         bb[j] = (two && p.bias_b) ? p.bias_b[c0 + j] : 0.f;
     }
-    auto elem = [&](int r, int j) -> float {                      // row r of the window, channel j
-        alignas(16) IO tmp[N];
-        *reinterpret_cast<uint4 *>(tmp) = raw[r];
-        return cm_elem<IO>::load(&tmp[j]);
+    auto elem = [&](int r, int j) -> float {
+        if constexpr (sizeof(IO) == 4) return __uint_as_float(raw[r]);
+        else return cm_elem<IO>::from_bits((uint16_t)(raw[r] >> (16 * j)));
+    };
+    auto pack = [&](const float (&o)[N]) -> uint32_t {
+        if constexpr (sizeof(IO) == 4) return __float_as_uint(o[0]);
+        else return (uint32_t)cm_elem<IO>::to_bits(o[0]) | ((uint32_t)cm_elem<IO>::to_bits(o[N - 1]) << 16);
     };
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const cm_conv_cl_args p, i
             of[j] = p.silu ? af * cm_sigmoid(af) : af;
             ob[j] = p.silu ? ab * cm_sigmoid(ab) : ab;
         }
-        vec8<IO>::store(yf + (int64_t)t * p.yf_ts, of);
-        if (two) vec8<IO>::store(yb + (int64_t)t * p.yb_ts, ob);
+        *reinterpret_cast<uint32_t *>(yf + (int64_t)t * p.yf_ts) = pack(of);
+        if (two) *reinterpret_cast<uint32_t *>(yb + (int64_t)t * p.yb_ts) = pack(ob);
     }
 }
 
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     const int D = p.dim, T = p.seqlen;
     const int b = blockIdx.y, t0 = blockIdx.x * tt;
     const int nin = tt + K - 1;                                   // input rows t0-K/2 .. t0+tt-1+K/2
-    float *g = sm;                                                // [nin][D]
-    float *co = sm + (size_t)nin * D;                             // [tt][D]
+    float *co = sm;                                               // [tt][D] fp32 conv outputs
+    IO *g = reinterpret_cast<IO *>(sm + (size_t)tt * D);          // [nin][D] GLU outputs in the I/O dtype
     const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * 2 * D;
     // phase 1: GLU rows -> LDS  (a = in[:, :D], gate = in[:, D:])
     constexpr int NV = cm_elem<IO>::kVec;
@@ -210,8 +214,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
 #pragma unroll
                 for (int j = 0; j < NV; ++j) av[j] = 0.f;
             }
-#pragma unroll
-            for (int j = 0; j < NV; j += 4) *reinterpret_cast<float4 *>(g + r * D + c + j) = make_float4(av[j], av[j + 1], av[j + 2], av[j + 3]);
+            vec8<IO>::store(g + r * D + c, av);
         }
     } else {
         for (int idx = threadIdx.x; idx < nin * D; idx += blockDim.x) {
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
                 const IO *row = in + (int64_t)t * 2 * D;
                 v0 = cm_elem<IO>::load(row + c) * cm_sigmoid(cm_elem<IO>::load(row + D + c));
             }
-            g[r * D + c] = v0;
+            cm_elem<IO>::store(g + r * D + c, v0);
         }
     }
     __syncthreads();
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
         const float bias = p.bias ? p.bias[c] : 0.f;
         float col[TT + K - 1];                                     // this channel's GLU outputs over the tile (+halo)
 #pragma unroll
-        for (int r = 0; r < TT + K - 1; ++r) col[r] = g[r * D + c];
+        for (int r = 0; r < TT + K - 1; ++r) col[r] = cm_elem<IO>::load(g + r * D + c);
 #pragma unroll
         for (int r = 0; r < TT; ++r) {
             float acc = bias;
@@ -383,13 +386,14 @@ extern "C" int cm_conv_cl_fwd(const cm_conv_cl_args *args) {
     CM_REQUIRE(a.width == 4, CM_EUNSUPPORTED, "conv_cl_fwd: width %d unsupported (4 only)", a.width);
     CM_REQUIRE(a.x && a.weight_f && a.y_fwd, CM_EINVAL, "conv_cl_fwd: x/weight_f/y_fwd must be non-NULL");
     CM_REQUIRE(!a.y_bwd || a.weight_b, CM_EINVAL, "conv_cl_fwd: y_bwd given without weight_b");
-    const int n = a.io_dtype == CM_F32 ? 4 : 8;
-    auto ok = [&](const void *ptr, int64_t bs, int64_t ts) { return !ptr || (cm_aligned(ptr, 16) && bs % n == 0 && ts % n == 0); };
+    const int n = a.io_dtype == CM_F32 ? 1 : 2;                    // channels per 32-bit word
+    auto ok = [&](const void *ptr, int64_t bs, int64_t ts) { return !ptr || (cm_aligned(ptr, 4) && bs % n == 0 && ts % n == 0); };
     CM_REQUIRE(a.dim % n == 0 && ok(a.x, a.x_bs, a.x_ts) && ok(a.y_fwd, a.yf_bs, a.yf_ts) && ok(a.y_bwd, a.yb_bs, a.yb_ts),
-               CM_EALIGN, "conv_cl_fwd: dim and strides must be multiples of %d elements, pointers 16-byte aligned", n);
+               CM_EALIGN, "conv_cl_fwd: dim and strides must be multiples of %d elements, pointers 4-byte aligned", n);
     const int vpr = a.dim / n;
     constexpr int tc = 8;
     const int64_t threads = (int64_t)a.batch * ((a.seqlen + tc - 1) / tc) * vpr;
+    CM_REQUIRE((threads + 255) / 256 <= 2147483647LL, CM_EINVAL, "conv_cl_fwd: problem too large");
     dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((conv_cl_kernel<cm_bf16, 4, tc>), grid, dim3(256), 0, st, a, vpr);
@@ -432,9 +436,11 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
     CM_REQUIRE(a.ksize == 31, CM_EUNSUPPORTED, "glu_dwconv: kernel size %d unsupported (31 only)", a.ksize);
     CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
     // time tile: LDS holds (tt + K - 1 + tt) rows of dim floats; keep it under 64 KB so 2 workgroups share a CU
+    const size_t el = a.io_dtype == CM_F32 ? 4 : 2;
+    auto lds_bytes = [&](int t) { return (size_t)t * a.dim * 4 + (size_t)(t + 30) * a.dim * el; };
     int tt = 16;
-    while (tt > 4 && (size_t)(2 * tt + 30) * a.dim * 4 > 64 * 1024) tt /= 2;
-    const size_t smem = (size_t)(2 * tt + 30) * a.dim * 4;
+    while (tt > 4 && lds_bytes(tt) > 64 * 1024) tt /= 2;
+    const size_t smem = lds_bytes(tt);
     dim3 grid((a.seqlen + tt - 1) / tt, a.batch);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     auto go = [&](auto kern) -> int {
