@@ -343,6 +343,9 @@ typedef struct cm_fbank_args {
     float amin, top_db;
     const float *mean, *std;     /* (n_mels) or NULL: used by cm_fbank_finish            */
     const int32_t *band_lo, *band_hi;   /* optional (n_mels): filter m is non-zero only on bins [lo, hi) */
+    int64_t spec_bs, spec_fs, spec_ts;  /* strides of spec in complex elements (batch, frequency, frame); all 0 =
+                                           contiguous (batch, n_freq, frames).  torch.stft hands out a transposed view
+                                           of a (batch, frames, n_freq) buffer: passing its strides avoids a 260 MB copy */
     void *stream;
 } cm_fbank_args;
 

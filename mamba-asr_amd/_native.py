@@ -118,7 +118,8 @@ class FbankArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
         ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
-        ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("stream", vp),
+        ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("spec_bs", i64), ("spec_fs", i64), ("spec_ts", i64),
+        ("stream", vp),
     ]
 
 

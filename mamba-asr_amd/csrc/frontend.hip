@@ -19,12 +19,15 @@ __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p
         band[m] = p.band_lo ? p.band_lo[m] : 0;
         band[M + m] = p.band_hi ? p.band_hi[m] : F;
     }
-    const float2 *spec = reinterpret_cast<const float2 *>(p.spec) + (int64_t)b * F * T;
+    const bool dflt = p.spec_bs == 0 && p.spec_fs == 0 && p.spec_ts == 0;
+    const int64_t sb = dflt ? (int64_t)F * T : p.spec_bs, sf = dflt ? T : p.spec_fs, st = dflt ? 1 : p.spec_ts;
+    const float2 *spec = reinterpret_cast<const float2 *>(p.spec) + (int64_t)b * sb;
+    const bool f_fast = sf < st;                                  // which axis is contiguous in memory
     for (int i = threadIdx.x; i < F * FT; i += blockDim.x) {
-        const int f = i / FT, j = i % FT;                         // consecutive threads -> consecutive frames (contiguous)
+        const int f = f_fast ? i % F : i / FT, j = f_fast ? i / F : i % FT;   // consecutive threads -> contiguous bytes
         float v = 0.f;
         if (t0 + j < T) {
-            const float2 c = spec[(int64_t)f * T + t0 + j];
+            const float2 c = spec[(int64_t)f * sf + (int64_t)(t0 + j) * st];
             v = c.x * c.x + c.y * c.y;
         }
         pw[f * FT + j] = v;

@@ -430,8 +430,9 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     features with the per-utterance top_db clamp and optional global normalisation (cm_fbank_mel_db + cm_fbank_finish)."""
     _dev_check(spec, fbank, mean, std)
     sr = torch.view_as_real(spec) if spec.is_complex() else spec
-    sr = sr.float().contiguous()
-    b, nf, t, _ = sr.shape
+    if sr.dtype != torch.float32 or sr.stride(3) != 1 or any(st % 2 for st in sr.stride()[:3]):
+        sr = sr.float().contiguous()
+    b, nf, t, _ = sr.shape                               # strided view accepted as is (no 260 MB transpose copy)
     fb = _f32c(fbank)
     m = fb.shape[1]
     db = torch.empty((b, t, m), dtype=torch.float32, device=sr.device)
@@ -443,6 +444,7 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     a.mean, a.std = _ptr(mean), _ptr(std)
     lo, hi = _mel_bands(fb)
     a.band_lo, a.band_hi = _ptr(lo), _ptr(hi)
+    a.spec_bs, a.spec_fs, a.spec_ts = sr.stride(0) // 2, sr.stride(1) // 2, sr.stride(2) // 2
     a.stream = _stream()
     _launch("cm_fbank_mel_db", N.lib().cm_fbank_mel_db, a, units=b * t)
     _launch("cm_fbank_finish", N.lib().cm_fbank_finish, a, units=b * t)
