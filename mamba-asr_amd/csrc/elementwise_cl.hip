@@ -274,65 +274,36 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 template <typename OT, int MAXPT>
-__global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_args p, int T1, int F1) {
-    __shared__ float rows[3][128 + 2];                 // input rows 2*t1-1 .. 2*t1+1 with reflect padding in F (F <= 128)
-    __shared__ float red[2][4];
+__global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_args p, int T1, int F1, int rpw) {
+    __shared__ float rows[2][3][128 + 2];              // input rows 2*t1-1 .. 2*t1+1 with reflect padding in F, double-buffered
+    __shared__ float red[2][2][4];
     __shared__ float wsh[128 * 9 + 128];               // conv taps [C][9] and bias [C] (C <= 128)
     const int C = p.C, F = p.F, T = p.T;
     const int P = p.pad_out;
-    const int tp = blockIdx.x, b = blockIdx.y;
-    const int t1 = reflect_idx(tp - P, T1);            // source output row (reflect border of the padded output)
+    const int b = blockIdx.y;
+    const int ntp = T1 + 2 * P;
+    const int tp0 = blockIdx.x * rpw, tp1 = min(tp0 + rpw, ntp);
     const float *feats = p.feats + (int64_t)b * T * F;
-    for (int i = threadIdx.x; i < 3 * (F + 2); i += blockDim.x) {
-        const int r = i / (F + 2), f = i % (F + 2);
-        const int tin = reflect_idx(2 * t1 + r - 1, T), fin = reflect_idx(f - 1, F);
-        rows[r][f] = feats[(int64_t)tin * F + fin];
-    }
+    const int n = F1 * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < C * 9; i += blockDim.x) wsh[i] = p.weight[i];
     for (int i = threadIdx.x; i < C; i += blockDim.x) wsh[C * 9 + i] = p.bias ? p.bias[i] : 0.f;
-    __syncthreads();
-    const int n = F1 * C;
-    float v[MAXPT];
-    float s = 0.f, sq = 0.f;
-    // thread owns channel PAIRS: o = 2*tid + 512*i -> (f1, c, c+1); C is even, so a pair never straddles f1
+    // LayerNorm parameters of this thread's outputs stay in registers for all rows of the workgroup
+    float lg[MAXPT], lb[MAXPT];
 #pragma unroll
     for (int i = 0; i < MAXPT / 2; ++i) {
         const int o = 2 * threadIdx.x + i * 512;
-        v[2 * i] = v[2 * i + 1] = 0.f;
-        if (o < n) {
-            const int f1 = o / C, c = o % C;
-            float a0 = wsh[C * 9 + c], a1 = wsh[C * 9 + c + 1];
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int df = 0; df < 3; ++df) {
-                    const float xin = rows[dt][2 * f1 + df];
-                    a0 = fmaf(wsh[c * 9 + dt * 3 + df], xin, a0);
-                    a1 = fmaf(wsh[(c + 1) * 9 + dt * 3 + df], xin, a1);
-                }
-            v[2 * i] = a0;
-            v[2 * i + 1] = a1;
-            s += a0 + a1;
-        }
+        lg[2 * i] = o < n ? p.ln_g[o] : 0.f; lg[2 * i + 1] = o < n ? p.ln_g[o + 1] : 0.f;
+        lb[2 * i] = o < n ? p.ln_b[o] : 0.f; lb[2 * i + 1] = o < n ? p.ln_b[o + 1] : 0.f;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    s = wave_sum(s);
-    if (lane == 0) red[0][wave] = s;
-    __syncthreads();
-    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
-#pragma unroll
-    for (int i = 0; i < MAXPT / 2; ++i) {
-        const int o = 2 * threadIdx.x + i * 512;
-        if (o < n) {
-            const float d0 = v[2 * i] - mean, d1 = v[2 * i + 1] - mean;
-            sq += d0 * d0 + d1 * d1;
+    auto load_rows = [&](int tp, int buf) {
+        const int t1 = reflect_idx(tp - P, T1);        // source output row (reflect border of the padded output)
+        for (int i = threadIdx.x; i < 3 * (F + 2); i += blockDim.x) {
+            const int r = i / (F + 2), f = i % (F + 2);
+            const int tin = reflect_idx(2 * t1 + r - 1, T), fin = reflect_idx(f - 1, F);
+            rows[buf][r][f] = feats[(int64_t)tin * F + fin];
         }
-    }
-    sq = wave_sum(sq);
-    if (lane == 0) red[1][wave] = sq;
-    __syncthreads();
-    const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n + p.eps);
-    OT *out = reinterpret_cast<OT *>(p.out) + ((int64_t)b * (T1 + 2 * P) + tp) * (F1 + 2 * P) * C;
+    };
     auto store2 = [&](OT *dst, float y0, float y1) {
         if constexpr (sizeof(OT) == 2) {
             *reinterpret_cast<uint32_t *>(dst) = (uint32_t)cm_elem<OT>::to_bits(y0) | ((uint32_t)cm_elem<OT>::to_bits(y1) << 16);
@@ -340,19 +311,58 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
             *reinterpret_cast<float2 *>(dst) = make_float2(y0, y1);
         }
     };
+    load_rows(tp0, 0);
+    __syncthreads();
+    for (int tp = tp0; tp < tp1; ++tp) {
+        const int buf = (tp - tp0) & 1;
+        if (tp + 1 < tp1) load_rows(tp + 1, buf ^ 1);  // next row's inputs while this row is computed
+        float v[MAXPT];
+        float s = 0.f, sq = 0.f;
+        // thread owns channel PAIRS: o = 2*tid + 512*i -> (f1, c, c+1); C is even, so a pair never straddles f1
 #pragma unroll
-    for (int i = 0; i < MAXPT / 2; ++i) {
-        const int o = 2 * threadIdx.x + i * 512;
-        if (o < n) {
-            const int f1 = o / C, c = o % C;
-            float y0 = (v[2 * i] - mean) * rstd * p.ln_g[o] + p.ln_b[o];
-            float y1 = (v[2 * i + 1] - mean) * rstd * p.ln_g[o + 1] + p.ln_b[o + 1];
-            y0 = y0 > 0.f ? y0 : p.slope * y0;
-            y1 = y1 > 0.f ? y1 : p.slope * y1;
-            store2(out + (f1 + P) * C + c, y0, y1);
-            if (P) {                                   // reflected frequency border: fp = 0 <- f1 = 1, fp = F1+1 <- f1 = F1-2
-                if (f1 == 1) store2(out + c, y0, y1);
-                if (f1 == F1 - 2) store2(out + (F1 + 1) * C + c, y0, y1);
+        for (int i = 0; i < MAXPT / 2; ++i) {
+            const int o = 2 * threadIdx.x + i * 512;
+            v[2 * i] = v[2 * i + 1] = 0.f;
+            if (o < n) {
+                const int f1 = o / C, c = o % C;
+                float a0 = wsh[C * 9 + c], a1 = wsh[C * 9 + c + 1];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const float xin = rows[buf][dt][2 * f1 + df];
+                        a0 = fmaf(wsh[c * 9 + dt * 3 + df], xin, a0);
+                        a1 = fmaf(wsh[(c + 1) * 9 + dt * 3 + df], xin, a1);
+                    }
+                v[2 * i] = a0;
+                v[2 * i + 1] = a1;
+                s += a0 + a1;
+                sq += a0 * a0 + a1 * a1;
+            }
+        }
+        // one block reduction for both moments (variance from E[x^2] - mean^2 in fp32: |x| = O(1) after input normalisation)
+        s = wave_sum(s);
+        sq = wave_sum(sq);
+        if (lane == 0) { red[buf][0][wave] = s; red[buf][1][wave] = sq; }
+        __syncthreads();                               // also orders next row's LDS inputs
+        const float mean = (red[buf][0][0] + red[buf][0][1] + red[buf][0][2] + red[buf][0][3]) / n;
+        const float ex2 = (red[buf][1][0] + red[buf][1][1] + red[buf][1][2] + red[buf][1][3]) / n;
+        const float rstd = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + p.eps);
+        OT *out = reinterpret_cast<OT *>(p.out) + ((int64_t)b * ntp + tp) * (F1 + 2 * P) * C;
+#pragma unroll
+        for (int i = 0; i < MAXPT / 2; ++i) {
+            const int o = 2 * threadIdx.x + i * 512;
+            if (o < n) {
+                const int f1 = o / C, c = o % C;
+                float y0 = (v[2 * i] - mean) * rstd * lg[2 * i] + lb[2 * i];
+                float y1 = (v[2 * i + 1] - mean) * rstd * lg[2 * i + 1] + lb[2 * i + 1];
+                y0 = y0 > 0.f ? y0 : p.slope * y0;
+                y1 = y1 > 0.f ? y1 : p.slope * y1;
+                store2(out + (f1 + P) * C + c, y0, y1);
+                if (P) {                               // reflected frequency border: fp = 0 <- f1 = 1, fp = F1+1 <- f1 = F1-2
+                    if (f1 == 1) store2(out + c, y0, y1);
+                    if (f1 == F1 - 2) store2(out + (F1 + 1) * C + c, y0, y1);
+                }
             }
         }
     }
@@ -369,10 +379,11 @@ extern "C" int cm_cnn_block1(const cm_cnn_block1_args *args) {
     CM_REQUIRE(a.pad_out == 0 || a.pad_out == 1, CM_EINVAL, "cnn_block1: pad_out must be 0 or 1");
     const int T1 = (a.T + 1) / 2, F1 = (a.F + 1) / 2;
     CM_REQUIRE(F1 * a.C <= 16 * 256 && T1 >= 3 && F1 >= 3, CM_EUNSUPPORTED, "cnn_block1: F1*C = %d unsupported (<= 4096)", F1 * a.C);
-    dim3 grid(T1 + 2 * a.pad_out, a.batch);
+    const int rpw = 8;                                              // output rows per workgroup
+    dim3 grid((T1 + 2 * a.pad_out + rpw - 1) / rpw, a.batch);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     const int pt = (F1 * a.C + 255) / 256;
-    auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a, T1, F1); };
+    auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a, T1, F1, rpw); };
     if (a.io_dtype == CM_BF16) { if (pt <= 10) launch(cnn_block1_kernel<cm_bf16, 10>); else launch(cnn_block1_kernel<cm_bf16, 16>); }
     else if (a.io_dtype == CM_F32) { if (pt <= 10) launch(cnn_block1_kernel<float, 10>); else launch(cnn_block1_kernel<float, 16>); }
     else { cm_set_error("cnn_block1: unsupported dtype %d", a.io_dtype); return CM_EUNSUPPORTED; }
