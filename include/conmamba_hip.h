@@ -270,6 +270,7 @@ typedef struct cm_glu_dwconv_args {
     int32_t pad2_;
     void *out;                   /* (batch, seqlen, dim), contiguous                   */
     void *stream;
+    const float *weight_t;       /* optional (ksize, dim) copy of the taps: per-channel reads become coalesced */
 } cm_glu_dwconv_args;
 
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
@@ -296,6 +297,28 @@ typedef struct cm_cnn_block1_args {
 } cm_cnn_block1_args;
 
 int cm_cnn_block1(const cm_cnn_block1_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * Second block of the CNN front end (same reference lines as cm_cnn_block1): Conv2d(64 -> 32, 3x3, stride 2,
+ * no padding -- the reflect border is already in the input) -> LayerNorm over (freq, channel) -> LeakyReLU, bf16.
+ *   in    : (batch, T_in, F_in, 64) bf16 channels-last  (cm_cnn_block1's output with pad_out = 1)
+ *   weight: (32, 3, 3, 64) bf16 -- output channel, tap row, tap column, input channel (a torch Conv2d weight in
+ *           channels_last memory format)
+ *   out   : (batch, T2, F2 * 32) bf16,  T2 = (T_in - 3) / 2 + 1,  F2 = (F_in - 3) / 2 + 1
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_cnn_block2_args {
+    int32_t batch, T_in, F_in, C_in, C_out;
+    int32_t pad_;
+    const void  *in;
+    const void  *weight;
+    const float *bias;           /* (32) or NULL                                           */
+    const float *ln_g, *ln_b;    /* (F2, 32)                                               */
+    float eps, slope;
+    void *out;
+    void *stream;
+} cm_cnn_block2_args;
+
+int cm_cnn_block2(const cm_cnn_block2_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogues for the ConMamba layer's projections:
@@ -325,6 +348,44 @@ typedef struct cm_gemm_args {
 int cm_gemm_bf16(const cm_gemm_args *args);
 
 /* ---------------------------------------------------------------------------------------
+ * Position-wise feed-forward module of a ConMamba layer, one kernel (reference modules/Conmamba.py:631-650 around
+ * speechbrain's PositionalwiseFeedForward: LayerNorm -> Linear(256, hidden) -> GELU -> Linear(hidden, 256), scaled
+ * residual, then the layer's next LayerNorm).  d_model is 256; hidden a multiple of 256.
+ *     xin   = x + add_scale * addend                (addend optional: the previous module's bf16 output)
+ *     r     = xin + alpha * (W2 gelu(W1 LN_pre(xin) + b1) + b2)
+ *     r     = LN_1(r)          if n1_g             (the layer's closing norm2)
+ *     x_out = r                if x_out            (fp32 residual stream; may alias x)
+ *     h_out = LN_2(r)          if h_out            (LN_2 skipped when n2_g is NULL), dtype h_dtype (bf16 or f32)
+ * The hidden activations stay in LDS; GEMM operands are bf16 with fp32 accumulation.
+ * w1 / w2 are passed in the PACKED layout produced by cm_ffn_pack_weights (once per weight update): the (R, K) matrix
+ * cut into 16-row x 32-column tiles, each stored as the 1 KB register image of an MFMA operand fragment -- element
+ * (r, k) of tile (r/16, k/32) sits at 16-bit index  tile*512 + ((k%32)/8*16 + r%16)*8 + k%8,  tile = (r/16)*(K/32) + k/32.
+ * ------------------------------------------------------------------------------------- */
+int cm_ffn_pack_weights(const void *w /* (rows, cols) bf16 row-major */, int32_t rows, int32_t cols,
+                        void *out /* rows*cols bf16 */, void *stream);
+
+typedef struct cm_ffn_args {
+    int32_t rows, dim, hidden;
+    int32_t h_dtype;                    /* CM_BF16 or CM_F32                                 */
+    const float *x;                     /* (rows, 256) fp32                                  */
+    const void  *addend;                /* (rows, 256) bf16 or NULL                          */
+    const float *pre_g, *pre_b;         /* (256) LayerNorm in front of the first Linear      */
+    const void  *w1;                    /* (hidden, 256) bf16, packed                        */
+    const float *b1;                    /* (hidden) fp32                                     */
+    const void  *w2;                    /* (256, hidden) bf16, packed                        */
+    const float *b2;                    /* (256) fp32                                        */
+    const float *n1_g, *n1_b;           /* optional LayerNorm applied to the stream          */
+    const float *n2_g, *n2_b;           /* optional LayerNorm producing h_out                */
+    float       *x_out;                 /* (rows, 256) fp32 or NULL                          */
+    void        *h_out;                 /* (rows, 256) h_dtype or NULL                       */
+    float add_scale, alpha, pre_eps, n1_eps, n2_eps;
+    int32_t pad_;
+    void *stream;
+} cm_ffn_args;
+
+int cm_ffn_fused(const cm_ffn_args *args);
+
+/* ---------------------------------------------------------------------------------------
  * Fbank back end (speechbrain Fbank semantics as used at reference train_CTC.py:285 and configured at
  * hparams/CTC/conmamba_large.yaml:322-326): STFT (re, im) -> power -> triangular mel filterbank -> 10*log10 with
  * floor `amin`, plus the per-utterance maximum needed by the top_db clamp.
@@ -343,6 +404,9 @@ typedef struct cm_fbank_args {
     float amin, top_db;
     const float *mean, *std;     /* (n_mels) or NULL: used by cm_fbank_finish            */
     const int32_t *band_lo, *band_hi;   /* optional (n_mels): filter m is non-zero only on bins [lo, hi) */
+    const int32_t *band_off;            /* optional (n_mels + 1): offsets into band_w                    */
+    const float   *band_w;              /* optional: filter m's weights for bins lo..hi-1, packed (sum of band widths
+                                           <= 4096 floats); staged in LDS instead of reading the dense matrix */
     int64_t spec_bs, spec_fs, spec_ts;  /* strides of spec in complex elements (batch, frequency, frame); all 0 =
                                            contiguous (batch, n_freq, frames).  torch.stft hands out a transposed view
                                            of a (batch, frames, n_freq) buffer: passing its strides avoids a 260 MB copy */

@@ -93,7 +93,7 @@ class GluDwconvArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("pad_", i32),
         ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
-        ("out", vp), ("stream", vp),
+        ("out", vp), ("stream", vp), ("weight_t", fp),
     ]
 
 
@@ -101,6 +101,14 @@ class CnnBlock1Args(C.Structure):
     _fields_ = [
         ("batch", i32), ("T", i32), ("F", i32), ("C", i32), ("io_dtype", i32), ("pad_out", i32),
         ("feats", fp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("slope", C.c_float),
+        ("out", vp), ("stream", vp),
+    ]
+
+
+class CnnBlock2Args(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("T_in", i32), ("F_in", i32), ("C_in", i32), ("C_out", i32), ("pad_", i32),
+        ("in_", vp), ("weight", vp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("slope", C.c_float),
         ("out", vp), ("stream", vp),
     ]
 
@@ -114,11 +122,21 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FfnArgs(C.Structure):
+    _fields_ = [
+        ("rows", i32), ("dim", i32), ("hidden", i32), ("h_dtype", i32),
+        ("x", fp), ("addend", vp), ("pre_g", fp), ("pre_b", fp), ("w1", vp), ("b1", fp), ("w2", vp), ("b2", fp),
+        ("n1_g", fp), ("n1_b", fp), ("n2_g", fp), ("n2_b", fp), ("x_out", fp), ("h_out", vp),
+        ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
+        ("pad_", i32), ("stream", vp),
+    ]
+
+
 class FbankArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
         ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
-        ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("spec_bs", i64), ("spec_fs", i64), ("spec_ts", i64),
+        ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("band_off", vp), ("band_w", fp), ("spec_bs", i64), ("spec_fs", i64), ("spec_ts", i64),
         ("stream", vp),
     ]
 
@@ -145,7 +163,10 @@ SYMBOLS = [
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
+    ("cm_cnn_block2", C.c_int, [C.POINTER(CnnBlock2Args)]),
     ("cm_gemm_bf16", C.c_int, [C.POINTER(GemmArgs)]),
+    ("cm_ffn_fused", C.c_int, [C.POINTER(FfnArgs)]),
+    ("cm_ffn_pack_weights", C.c_int, [vp, i32, i32, vp, vp]),
     ("cm_fbank_mel_db", C.c_int, [C.POINTER(FbankArgs)]),
     ("cm_fbank_finish", C.c_int, [C.POINTER(FbankArgs)]),
     ("cm_spec_drop", C.c_int, [C.POINTER(SpecDropArgs)]),

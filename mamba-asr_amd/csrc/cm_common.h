@@ -78,6 +78,21 @@ __device__ __forceinline__ float cm_exp2(float x) { return __builtin_amdgcn_exp2
 __device__ __forceinline__ float cm_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float cm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float cm_sigmoid(float x) { return cm_rcp(1.0f + cm_exp2(-CM_LOG2E * x)); }
+// GELU, erf form (torch.nn.GELU default; reference Conmamba.py FFN / convolution module activations):
+// 0.5 x erfc(-x / sqrt 2) with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, no cancellation on
+// the negative side) -- ~14 issue slots instead of the ~45 of libm's erff, which made GELU the pace-setter of the
+// kernels that end in it.
+__device__ __forceinline__ float cm_gelu(float x) {
+    const float s = fabsf(x) * 0.70710678118654752f;
+    const float t = cm_rcp(fmaf(0.3275911f, s, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = poly * t * cm_exp2(-CM_LOG2E * s * s);        // erfc(|x| / sqrt 2)
+    return 0.5f * x * (x >= 0.f ? 2.0f - e : e);
+}
+
 // softplus, beta=1, threshold=20 (torch default; reference selective_scan_interface.py:112).
 // For x < -15, log1p(e^x) == e^x to fp32 precision; using it avoids the 1+tiny cancellation.
 __device__ __forceinline__ float cm_softplus(float x) {

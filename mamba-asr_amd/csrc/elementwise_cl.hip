@@ -23,7 +23,7 @@ template <typename IO> struct vec8 {                  // 16-byte vector of IO el
     }
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return cm_gelu(x); }
 
 // ------------------------------------------------------------------------------------------------
 // conv, both directions.  One thread owns one 16-byte channel vector and walks a run of TC steps with a
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     const int D = p.dim, T = p.seqlen;
     const int b = blockIdx.y, t0 = blockIdx.x * tt;
     const int nin = tt + K - 1;                                   // input rows t0-K/2 .. t0+tt-1+K/2
-    float *co = sm;                                               // [tt][D] fp32 conv outputs
-    IO *g = reinterpret_cast<IO *>(sm + (size_t)tt * D);          // [nin][D] GLU outputs in the I/O dtype
+    const int CS = D + 16;                                        // co row stride: rows of one wave land in different banks
+    float *co = sm;                                               // [tt][CS] fp32 conv outputs
+    IO *g = reinterpret_cast<IO *>(sm + (size_t)tt * CS);         // [nin][D] GLU outputs in the I/O dtype
     const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * 2 * D;
     // phase 1: GLU rows -> LDS  (a = in[:, :D], gate = in[:, D:])
     constexpr int NV = cm_elem<IO>::kVec;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         float w[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) w[k] = p.weight[c * K + k];
+        for (int k = 0; k < K; ++k) w[k] = p.weight_t ? p.weight_t[k * D + c] : p.weight[c * K + k];   // (K, D): coalesced
         const float bias = p.bias ? p.bias[c] : 0.f;
         float col[TT + K - 1];                                     // this channel's GLU outputs over the tile (+halo)
 #pragma unroll
@@ -243,24 +244,60 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
             float acc = bias;
 #pragma unroll
             for (int k = 0; k < K; ++k) acc = fmaf(w[k], col[r + k], acc);
-            co[r * D + c] = acc;
+            co[r * CS + c] = acc;
         }
     }
     __syncthreads();
-    // phase 3: LayerNorm + GELU per row, one wave per row
+    // phase 3: LayerNorm + GELU per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     IO *out = reinterpret_cast<IO *>(p.out) + (int64_t)b * T * D;
+    if (D == 256) {
+        // a row of 16 lanes per LayerNorm row (16 values per lane): statistics by in-lane adds + 4 DPP steps, four rows
+        // per wave instruction, 8/16-byte stores that are contiguous over the 16 lanes
+        const int l15 = lane & 15, lq = lane >> 4;
+        for (int r = wave * 4 + lq; r < tt; r += 16) {
+            const int t = t0 + r;
+            float4 v[4];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = *reinterpret_cast<const float4 *>(co + r * CS + 4 * (l15 + 16 * i));
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+            const float mean = cm_group_sum<16>(s) * (1.f / 256);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                sq = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, sq))));
+            }
+            const float rstd = rsqrtf(cm_group_sum<16>(sq) * (1.f / 256) + p.eps);
+            if (t < T) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * (l15 + 16 * i);
+                    const float4 gm = *reinterpret_cast<const float4 *>(p.ln_g + c);
+                    const float4 bt = *reinterpret_cast<const float4 *>(p.ln_b + c);
+                    float o[4] = {gelu_erf(fmaf(v[i].x * rstd, gm.x, bt.x)), gelu_erf(fmaf(v[i].y * rstd, gm.y, bt.y)),
+                                  gelu_erf(fmaf(v[i].z * rstd, gm.z, bt.z)), gelu_erf(fmaf(v[i].w * rstd, gm.w, bt.w))};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cm_elem<IO>::store(out + (int64_t)t * D + c + j, o[j]);
+                }
+            }
+        }
+        return;
+    }
     for (int r = wave; r < tt; r += 4) {
         const int t = t0 + r;
         if (t >= T) break;
         float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += co[r * D + c];
+        for (int c = lane; c < D; c += 64) s += co[r * CS + c];
         const float mean = wave_sum(s) / D;
         float sq = 0.f;
-        for (int c = lane; c < D; c += 64) { const float dl = co[r * D + c] - mean; sq += dl * dl; }
+        for (int c = lane; c < D; c += 64) { const float dl = co[r * CS + c] - mean; sq += dl * dl; }
         const float rstd = rsqrtf(wave_sum(sq) / D + p.eps);
         for (int c = lane; c < D; c += 64) {
-            const float v = (co[r * D + c] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
+            const float v = (co[r * CS + c] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
             cm_elem<IO>::store(out + (int64_t)t * D + c, gelu_erf(v));
         }
     }
@@ -296,6 +333,13 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
         lg[2 * i] = o < n ? p.ln_g[o] : 0.f; lg[2 * i + 1] = o < n ? p.ln_g[o + 1] : 0.f;
         lb[2 * i] = o < n ? p.ln_b[o] : 0.f; lb[2 * i + 1] = o < n ? p.ln_b[o + 1] : 0.f;
     }
+    // o = 2*tid + 512*i: when C divides 512 the channel pair (c, c+1) is the same for every i -> taps in registers
+    const bool reg_taps = (512 % C) == 0;
+    const int c_fix = (2 * threadIdx.x) % C;
+    float wr0[9], wr1[9], br0 = 0.f, br1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wr0[k] = p.weight[c_fix * 9 + k]; wr1[k] = p.weight[(c_fix + 1) * 9 + k]; }
+    if (p.bias) { br0 = p.bias[c_fix]; br1 = p.bias[c_fix + 1]; }
     auto load_rows = [&](int tp, int buf) {
         const int t1 = reflect_idx(tp - P, T1);        // source output row (reflect border of the padded output)
         for (int i = threadIdx.x; i < 3 * (F + 2); i += blockDim.x) {
@@ -325,15 +369,28 @@ __global__ __launch_bounds__(256) void cnn_block1_kernel(const cm_cnn_block1_arg
             v[2 * i] = v[2 * i + 1] = 0.f;
             if (o < n) {
                 const int f1 = o / C, c = o % C;
-                float a0 = wsh[C * 9 + c], a1 = wsh[C * 9 + c + 1];
+                float a0, a1;
+                if (reg_taps) {
+                    a0 = br0; a1 = br1;
 #pragma unroll
-                for (int dt = 0; dt < 3; ++dt)
+                    for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-                    for (int df = 0; df < 3; ++df) {
-                        const float xin = rows[buf][dt][2 * f1 + df];
-                        a0 = fmaf(wsh[c * 9 + dt * 3 + df], xin, a0);
-                        a1 = fmaf(wsh[(c + 1) * 9 + dt * 3 + df], xin, a1);
-                    }
+                        for (int df = 0; df < 3; ++df) {
+                            const float xin = rows[buf][dt][2 * f1 + df];
+                            a0 = fmaf(wr0[dt * 3 + df], xin, a0);
+                            a1 = fmaf(wr1[dt * 3 + df], xin, a1);
+                        }
+                } else {
+                    a0 = wsh[C * 9 + c]; a1 = wsh[C * 9 + c + 1];
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                        for (int df = 0; df < 3; ++df) {
+                            const float xin = rows[buf][dt][2 * f1 + df];
+                            a0 = fmaf(wsh[c * 9 + dt * 3 + df], xin, a0);
+                            a1 = fmaf(wsh[(c + 1) * 9 + dt * 3 + df], xin, a1);
+                        }
+                }
                 v[2 * i] = a0;
                 v[2 * i + 1] = a1;
                 s += a0 + a1;
@@ -448,7 +505,7 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
     CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
     // time tile: LDS holds (tt + K - 1 + tt) rows of dim floats; keep it under 64 KB so 2 workgroups share a CU
     const size_t el = a.io_dtype == CM_F32 ? 4 : 2;
-    auto lds_bytes = [&](int t) { return (size_t)t * a.dim * 4 + (size_t)(t + 30) * a.dim * el; };
+    auto lds_bytes = [&](int t) { return (size_t)t * (a.dim + 16) * 4 + (size_t)(t + 30) * a.dim * el; };
     int tt = 16;
     while (tt > 4 && lds_bytes(tt) > 64 * 1024) tt /= 2;
     const size_t smem = lds_bytes(tt);

@@ -1,0 +1,386 @@
+// ffn_fused.hip — the whole position-wise feed-forward module of a ConMamba layer as ONE kernel
+// (contract: cm_ffn_fused in include/conmamba_hip.h; reference modules/Conmamba.py:631-650 around
+// PositionalwiseFeedForward: x + 0.5 * W2 gelu(W1 LN(x) + b1) + b2, then the layer's next LayerNorm).
+//
+// Through the vendor library this module was LayerNorm kernel -> GEMM (rows x 1024 hidden written to HBM) -> GEMM
+// (hidden read back) -> residual + LayerNorm kernel, and the two small-K GEMMs ran at 1-2 TB/s of effective traffic.
+// Here a workgroup owns 64 tokens end to end: the hidden activations never leave the CU.
+//   * d_model = 256.  Four waves; LDS holds the normalised tokens (64 x 256 bf16) and one 256-wide slab of hidden
+//     activations (64 x 256 bf16), rows padded to 528 B so ds_read_b128 fragments are conflict-free.
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the A operand and tokens as the B operand: a lane's accumulator
+//     registers are 4 consecutive features of one token, so the hidden slab is written back with 8-byte LDS stores,
+//     the output with 16-byte global stores, and the LayerNorm statistics need two cross-lane adds per token.
+//   * each wave computes a 64-feature x 64-token tile (4 x 4 MFMA tiles): weight fragments come straight from
+//     global memory (L2-resident, 1 MB per FFN) into a 4-deep register ring that runs across both GEMMs and across
+//     slabs -- every weight byte is loaded by exactly one wave of the workgroup and never touches LDS; token fragments
+//     come from LDS, 4 ds_read_b128 per 16 MFMAs (64 B/clk/CU at full MFMA rate).
+//   * barriers wait on LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier), so the weight ring is not drained.
+#include "cm_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int D = 256;        // d_model
+constexpr int TOK = 64;       // tokens per workgroup
+constexpr int XS = 264;       // LDS row stride in bf16 elements (528 bytes)
+constexpr int CH = 256;       // hidden slab
+constexpr int PF = 4;         // weight-fragment ring depth (k-steps in flight)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return (uint32_t)cm_elem<cm_bf16>::to_bits(a) | ((uint32_t)cm_elem<cm_bf16>::to_bits(b) << 16);
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
+    uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab
+    float *red = reinterpret_cast<float *>(hc + TOK * XS);        // [4][TOK] LayerNorm partial sums
+    float *b1s = red + 4 * TOK;                                   // [hidden] first bias (a global load inside the slab
+                                                                  // loop would wait on vmcnt and drain the weight ring)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // uniform: it feeds the buffer loads' scalar offset
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int t0 = blockIdx.x * TOK, M = p.rows, F = p.hidden;
+    const int nch = F / CH;
+    const uint16_t *W1 = reinterpret_cast<const uint16_t *>(p.w1);
+    const uint16_t *W2 = reinterpret_cast<const uint16_t *>(p.w2);
+    const uint16_t *addend = reinterpret_cast<const uint16_t *>(p.addend);
+
+    // ---- weight stream.  Step s of slab c: s < 8  -> W1 rows c*CH + wave*64 + mb*16 + l15, columns s*32 + lq*8
+    //                                        s >= 8 -> W2 rows wave*64 + mb*16 + l15, columns c*CH + (s-8)*32 + lq*8
+    // Weights are PACKED (cm_ffn_pack_weights): 16-row x 32-column tiles, each stored as the 1 KB image of one MFMA
+    // operand fragment (lane L = lq*16 + l15 owns bytes [16 L, 16 L + 16)), tiles of one 16-row band contiguous over
+    // the columns.  A wave-level fragment load is then ONE contiguous kilobyte (8 full cache lines) instead of 16 half
+    // lines from 16 rows -- the row-major version of this kernel was bound by L1 tag lookups (9 B/clk/CU).
+    // Buffer loads: one VGPR of lane offset, everything else in SGPRs / the immediate field.
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(W1), 0, F * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(W2), 0, F * D * 2, 0x00020000);
+    const int vl = lane * 16;
+    const int kt2 = F / 32;                                       // tiles per 16-row band of W2
+    auto wload = [&](int c, int s, bf16x8(&dst)[4]) {
+        if (s < 8) {                                              // W1 band (c*CH + wave*64)/16 + mb, tile s
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                dst[mb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         r1, vl, (((c * CH + wave * 64) / 16 + mb) * (D / 32) + s) * 1024, 0));
+        } else {                                                  // W2 band wave*4 + mb, tile c*CH/32 + (s-8)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                dst[mb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         r2, vl, ((wave * 4 + mb) * kt2 + c * (CH / 32) + (s - 8)) * 1024, 0));
+        }
+    };
+    bf16x8 wq[PF][4];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) wload(0, s, wq[s]);
+
+    for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
+
+    // ---- phase 0: xin = x (+ add_scale * addend); xn = LayerNorm_pre(xin) in bf16.
+    // Wave w owns tokens 16w .. 16w+15, four per round: a row of 16 lanes holds one token (16 floats per lane), so the
+    // statistics are in-lane adds + four full-rate DPP steps (no LDS-crossbar shuffles), and all 16 loads of the wave
+    // are in flight together.
+    auto load_x4 = [&](int tok, int col) {
+        float4 v = *reinterpret_cast<const float4 *>(p.x + (int64_t)tok * D + col);
+        if constexpr (ADD) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(addend + (int64_t)tok * D + col);
+            v.x = fmaf(p.add_scale, __uint_as_float(a.x << 16), v.x);
+            v.y = fmaf(p.add_scale, __uint_as_float(a.x & 0xffff0000u), v.y);
+            v.z = fmaf(p.add_scale, __uint_as_float(a.y << 16), v.z);
+            v.w = fmaf(p.add_scale, __uint_as_float(a.y & 0xffff0000u), v.w);
+        }
+        return v;
+    };
+    {
+        float4 v[4][4];
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int tok = min(t0 + wave * 16 + rd * 4 + lq, M - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[rd][i] = load_x4(tok, (l15 + 16 * i) * 4);
+        }
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += (v[rd][i].x + v[rd][i].y) + (v[rd][i].z + v[rd][i].w);
+            const float mean = cm_group_sum<16>(s) * (1.f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[rd][i].x -= mean; v[rd][i].y -= mean; v[rd][i].z -= mean; v[rd][i].w -= mean;
+                q = fmaf(v[rd][i].x, v[rd][i].x, fmaf(v[rd][i].y, v[rd][i].y, fmaf(v[rd][i].z, v[rd][i].z, fmaf(v[rd][i].w, v[rd][i].w, q))));
+            }
+            const float rstd = rsqrtf(cm_group_sum<16>(q) * (1.f / D) + p.pre_eps);
+            uint16_t *dst = xn + (wave * 16 + rd * 4 + lq) * XS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = (l15 + 16 * i) * 4;
+                const float4 g = *reinterpret_cast<const float4 *>(p.pre_g + col);
+                const float4 b = *reinterpret_cast<const float4 *>(p.pre_b + col);
+                uint2 pk;
+                pk.x = pack2(fmaf(v[rd][i].x * rstd, g.x, b.x), fmaf(v[rd][i].y * rstd, g.y, b.y));
+                pk.y = pack2(fmaf(v[rd][i].z * rstd, g.z, b.z), fmaf(v[rd][i].w * rstd, g.w, b.w));
+                *reinterpret_cast<uint2 *>(dst + col) = pk;
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- main loop over hidden slabs
+    f32x4 acc2[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint16_t *xfrag = xn + l15 * XS + lq * 8;
+    const uint16_t *hfrag = hc + l15 * XS + lq * 8;
+    uint16_t *hdst = hc + l15 * XS + wave * 64 + lq * 4;
+
+    auto read_frags = [&](const uint16_t *base, int ks, bf16x8(&bf)[4]) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const bf16x8 *>(base + nb * 16 * XS + ks * 32);
+    };
+    const int f0 = wave * 64 + lq * 4;
+    float r[4][4][4];                                             // epilogue: [token tile][feature tile][4 features]
+    // one hidden slab; the last one is peeled (LAST) so that the residual rows it prefetches are not live in the loop
+    auto slab = [&](const int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        f32x4 acc1[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc1[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // GEMM 1: hidden slab (this wave: 64 hidden units) x 64 tokens, K = 256.  Token fragments of step s+1 are
+        // read from LDS while the MFMAs of step s run.
+        bf16x8 bfa[4], bfb[4];
+        read_frags(xfrag, 0, bfa);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+            bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
+            if (s + 1 < 8) read_frags(xfrag, s + 1, nxt);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc1[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc1[mb][nb], 0, 0, 0);
+            wload(c, s + PF, wq[s % PF]);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the refill HERE: the scheduler otherwise sinks
+        }                                                         // the loads to their use and the ring is gone
+        // bias + GELU -> bf16 slab in LDS (token-major, hidden contiguous)
+        if (c > 0) lds_barrier();                                 // every wave is done reading the previous slab
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 bv = *reinterpret_cast<const float4 *>(b1s + c * CH + wave * 64 + mb * 16 + lq * 4);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                uint2 pk;
+                pk.x = pack2(cm_gelu(acc1[mb][nb][0] + bv.x), cm_gelu(acc1[mb][nb][1] + bv.y));
+                pk.y = pack2(cm_gelu(acc1[mb][nb][2] + bv.z), cm_gelu(acc1[mb][nb][3] + bv.w));
+                *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
+            }
+        }
+        lds_barrier();
+        if constexpr (LAST) {                                     // residual rows for the epilogue: in flight under GEMM 2
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int tok = min(t0 + nb * 16 + l15, M - 1);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float4 xv = load_x4(tok, f0 + mb * 16);
+                    r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
+                }
+            }
+        }
+        // GEMM 2: 64 output features x 64 tokens, K = this slab
+        read_frags(hfrag, 0, bfa);
+#pragma unroll
+        for (int s = 8; s < 16; ++s) {
+            bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+            bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
+            if (s + 1 < 16) read_frags(hfrag, s + 1 - 8, nxt);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc2[mb][nb], 0, 0, 0);
+            if (s + PF < 16) wload(c, s + PF, wq[s % PF]);
+            else if constexpr (!LAST) wload(c + 1, s + PF - 16, wq[s % PF]);   // next slab's first steps
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int c = 0; c + 1 < nch; ++c) slab(c, std::false_type{});
+    slab(nch - 1, std::true_type{});
+
+    // ---- epilogue: r = xin + alpha (acc2 + b2); optional LN1 -> stream; optional LN2 -> h_out.
+    // Lane holds token nb*16 + l15, features wave*64 + mb*16 + lq*4 + j.
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + f0 + mb * 16);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            r[nb][mb][0] = fmaf(p.alpha, acc2[mb][nb][0] + bv.x, r[nb][mb][0]);
+            r[nb][mb][1] = fmaf(p.alpha, acc2[mb][nb][1] + bv.y, r[nb][mb][1]);
+            r[nb][mb][2] = fmaf(p.alpha, acc2[mb][nb][2] + bv.z, r[nb][mb][2]);
+            r[nb][mb][3] = fmaf(p.alpha, acc2[mb][nb][3] + bv.w, r[nb][mb][3]);
+        }
+    }
+    // sum over a token's 256 features: 16 in-lane, 4 lane groups, 4 waves (through LDS)
+    auto token_sums = [&](float (&v)[4]) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            v[nb] += __shfl_xor(v[nb], 16, 64);
+            v[nb] += __shfl_xor(v[nb], 32, 64);
+        }
+        lds_barrier();                                            // previous use of red is over
+        if (lq == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) red[wave * TOK + nb * 16 + l15] = v[nb];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int t = nb * 16 + l15;
+            v[nb] = (red[t] + red[TOK + t]) + (red[2 * TOK + t] + red[3 * TOK + t]);
+        }
+    };
+    auto layer_norm = [&](const float *g, const float *b, float eps) {
+        float s[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            s[nb] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) s[nb] += (r[nb][mb][0] + r[nb][mb][1]) + (r[nb][mb][2] + r[nb][mb][3]);
+        }
+        token_sums(s);
+        float q[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            s[nb] *= (1.f / D);
+            q[nb] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = r[nb][mb][j] - s[nb]; q[nb] = fmaf(d, d, q[nb]); }
+        }
+        token_sums(q);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 gv = *reinterpret_cast<const float4 *>(g + f0 + mb * 16);
+            const float4 bv = *reinterpret_cast<const float4 *>(b + f0 + mb * 16);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float rstd = rsqrtf(q[nb] * (1.f / D) + eps);
+                r[nb][mb][0] = fmaf((r[nb][mb][0] - s[nb]) * rstd, gv.x, bv.x);
+                r[nb][mb][1] = fmaf((r[nb][mb][1] - s[nb]) * rstd, gv.y, bv.y);
+                r[nb][mb][2] = fmaf((r[nb][mb][2] - s[nb]) * rstd, gv.z, bv.z);
+                r[nb][mb][3] = fmaf((r[nb][mb][3] - s[nb]) * rstd, gv.w, bv.w);
+            }
+        }
+    };
+    if (p.n1_g) layer_norm(p.n1_g, p.n1_b, p.n1_eps);
+    if (p.x_out) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int tok = t0 + nb * 16 + l15;
+            if (tok < M) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    *reinterpret_cast<float4 *>(p.x_out + (int64_t)tok * D + f0 + mb * 16) =
+                        make_float4(r[nb][mb][0], r[nb][mb][1], r[nb][mb][2], r[nb][mb][3]);
+            }
+        }
+    }
+    if (p.h_out) {
+        if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int tok = t0 + nb * 16 + l15;
+            if (tok < M) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    if (p.h_dtype == CM_F32) {
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.h_out) + (int64_t)tok * D + f0 + mb * 16) =
+                            make_float4(r[nb][mb][0], r[nb][mb][1], r[nb][mb][2], r[nb][mb][3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = pack2(r[nb][mb][0], r[nb][mb][1]);
+                        pk.y = pack2(r[nb][mb][2], r[nb][mb][3]);
+                        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.h_out) + (int64_t)tok * D + f0 + mb * 16) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// row-major (R, K) bf16 -> fragment-tiled image (see ffn_fused_kernel).  One thread per 16-byte piece.
+__global__ void ffn_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ out, int R, int K) {
+    const int64_t piece = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // = tile * 64 + lane
+    const int64_t npieces = (int64_t)R * K / 8;
+    if (piece >= npieces) return;
+    const int lane = (int)(piece & 63);
+    const int64_t tile = piece >> 6;
+    const int kt = K / 32;
+    const int rb = (int)(tile / kt), kb = (int)(tile % kt);
+    const int r = rb * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<uint4 *>(out + piece * 8) = *reinterpret_cast<const uint4 *>(w + (int64_t)r * K + k);
+}
+
+template <bool ADD>
+int launch(const cm_ffn_args &a) {
+    const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)4 * TOK * sizeof(float) + (size_t)a.hidden * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<ADD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) {
+            cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_done = true;
+    }
+    dim3 grid((a.rows + TOK - 1) / TOK);
+    hipLaunchKernelGGL((ffn_fused_kernel<ADD>), grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_ffn_fused");
+}
+
+}  // namespace
+
+extern "C" int cm_ffn_pack_weights(const void *w, int32_t rows, int32_t cols, void *out, void *stream) {
+    CM_REQUIRE(w && out && rows > 0 && cols > 0, CM_EINVAL, "ffn_pack_weights: bad sizes or NULL tensor");
+    CM_REQUIRE(rows % 16 == 0 && cols % 32 == 0, CM_EUNSUPPORTED, "ffn_pack_weights: needs rows %% 16 == 0 and cols %% 32 == 0");
+    CM_REQUIRE(cm_aligned(w, 16) && cm_aligned(out, 16) && w != out, CM_EALIGN, "ffn_pack_weights: tensors must be distinct and 16-byte aligned");
+    const int64_t npieces = (int64_t)rows * cols / 8;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint16_t *>(w), reinterpret_cast<uint16_t *>(out), rows, cols);
+    return cm_launch_status("cm_ffn_pack_weights");
+}
+
+extern "C" int cm_ffn_fused(const cm_ffn_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "ffn_fused: args is NULL");
+    const cm_ffn_args &a = *args;
+    CM_REQUIRE(a.rows > 0 && a.x && a.w1 && a.b1 && a.w2 && a.b2 && a.pre_g && a.pre_b, CM_EINVAL,
+               "ffn_fused: bad sizes or NULL tensor");
+    CM_REQUIRE(a.dim == D, CM_EUNSUPPORTED, "ffn_fused: d_model must be 256 (got %d)", a.dim);
+    CM_REQUIRE(a.hidden >= CH && a.hidden % CH == 0 && a.hidden <= 2048, CM_EUNSUPPORTED,
+               "ffn_fused: hidden must be a multiple of 256, at most 2048 (got %d)", a.hidden);
+    CM_REQUIRE((!a.n1_g || a.n1_b) && (!a.n2_g || a.n2_b), CM_EINVAL, "ffn_fused: LayerNorm weight without bias");
+    CM_REQUIRE(a.x_out || a.h_out, CM_EINVAL, "ffn_fused: neither x_out nor h_out given");
+    CM_REQUIRE(!a.h_out || a.h_dtype == CM_F32 || a.h_dtype == CM_BF16, CM_EINVAL, "ffn_fused: h_dtype must be f32 or bf16");
+    CM_REQUIRE(cm_aligned(a.x, 16) && cm_aligned(a.w1, 16) && cm_aligned(a.w2, 16) && cm_aligned(a.b1, 16) && cm_aligned(a.b2, 16) &&
+                   cm_aligned(a.pre_g, 16) && cm_aligned(a.pre_b, 16) && (!a.x_out || cm_aligned(a.x_out, 16)) &&
+                   (!a.h_out || cm_aligned(a.h_out, 16)) && (!a.addend || cm_aligned(a.addend, 8)) &&
+                   (!a.n1_g || (cm_aligned(a.n1_g, 16) && cm_aligned(a.n1_b, 16))) &&
+                   (!a.n2_g || (cm_aligned(a.n2_g, 16) && cm_aligned(a.n2_b, 16))),
+               CM_EALIGN, "ffn_fused: tensors must be 16-byte aligned");
+    return a.addend ? launch<true>(a) : launch<false>(a);
+}

@@ -9,15 +9,24 @@ namespace {
 // power spectrum of the tile is staged in LDS [n_freq][16]; the mel filterbank is sparse (triangles), but a dense
 // 257 x 80 product per frame is only 41 kFLOP: HBM traffic (reading the complex spectrum once) dominates.
 constexpr int FT = 16;
+constexpr int PWS = FT + 1;   // LDS row stride of the power tile: odd, so different bins of one frame sit in different banks
+                              // (stride 16 put all bins of a frame in 4 banks: the mel loop ran 16-way conflicted)
 
 __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p) {
     extern __shared__ float pw[];                                 // [n_freq][FT] then [2][n_mels] band limits
     const int b = blockIdx.y, t0 = blockIdx.x * FT;
     const int F = p.n_freq, T = p.frames, M = p.n_mels;
-    int *band = reinterpret_cast<int *>(pw + F * FT);             // triangular filters are contiguous bands: [lo, hi)
+    int *band = reinterpret_cast<int *>(pw + F * PWS);             // triangular filters are contiguous bands: [lo, hi)
+    float *bw = reinterpret_cast<float *>(band + 3 * M + 1);      // packed band weights (when provided)
+    const bool packed = p.band_w != nullptr && p.band_off != nullptr && p.band_lo != nullptr;
     for (int m = threadIdx.x; m < M; m += blockDim.x) {           // triangular filters: contiguous bands (host-provided)
         band[m] = p.band_lo ? p.band_lo[m] : 0;
         band[M + m] = p.band_hi ? p.band_hi[m] : F;
+    }
+    if (packed) {
+        for (int m = threadIdx.x; m <= M; m += blockDim.x) band[2 * M + m] = p.band_off[m];
+        const int total = p.band_off[M];
+        for (int i = threadIdx.x; i < total; i += blockDim.x) bw[i] = p.band_w[i];
     }
     const bool dflt = p.spec_bs == 0 && p.spec_fs == 0 && p.spec_ts == 0;
     const int64_t sb = dflt ? (int64_t)F * T : p.spec_bs, sf = dflt ? T : p.spec_fs, st = dflt ? 1 : p.spec_ts;
@@ -30,7 +39,7 @@ __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p
             const float2 c = spec[(int64_t)f * sf + (int64_t)(t0 + j) * st];
             v = c.x * c.x + c.y * c.y;
         }
-        pw[f * FT + j] = v;
+        pw[f * PWS + j] = v;
     }
     __syncthreads();
     float local_max = -INFINITY;
@@ -38,7 +47,13 @@ __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p
         const int j = o / M, m = o % M;                           // consecutive threads -> consecutive mels (coalesced store)
         if (t0 + j >= T) continue;
         float acc = 0.f;
-        for (int f = band[m]; f < band[M + m]; ++f) acc = fmaf(pw[f * FT + j], p.fbank[f * M + m], acc);
+        const int lo = band[m], hi = band[M + m];
+        if (packed) {                                             // LDS-only inner loop (no dependent global loads)
+            const float *wm = bw + band[2 * M + m] - lo;
+            for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], wm[f], acc);
+        } else {
+            for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], p.fbank[f * M + m], acc);
+        }
         const float db = 10.f * log10f(fmaxf(acc, p.amin));
         p.db[((int64_t)b * T + t0 + j) * M + m] = db;
         local_max = fmaxf(local_max, db);
@@ -88,7 +103,7 @@ extern "C" int cm_fbank_mel_db(const cm_fbank_args *args) {
     const cm_fbank_args &a = *args;
     CM_REQUIRE(a.batch > 0 && a.n_freq > 0 && a.frames > 0 && a.n_mels > 0 && a.spec && a.fbank && a.db && a.umax, CM_EINVAL,
                "fbank_mel_db: bad sizes or NULL tensor");
-    const size_t smem = (size_t)a.n_freq * FT * 4 + (size_t)2 * a.n_mels * 4;
+    const size_t smem = (size_t)a.n_freq * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (a.band_w ? (size_t)4096 * 4 : 0);
     CM_REQUIRE(a.batch <= 65535 && smem <= 64 * 1024, CM_EUNSUPPORTED, "fbank_mel_db: n_freq %d too large", a.n_freq);
     dim3 grid((a.frames + FT - 1) / FT, a.batch);
     hipLaunchKernelGGL(fbank_mel_db_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);

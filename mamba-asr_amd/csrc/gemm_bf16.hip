@@ -23,7 +23,7 @@ constexpr int BM = 64, BN = 256, BK = 64;
 constexpr int LDSROW = 80;                       // elements per LDS weight row (64 + 16 pad) = 160 bytes
 constexpr int TILE_ELEMS = BN * LDSROW;          // one buffered weight tile
 
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return cm_gelu(x); }
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const cm_gemm_args p) {

@@ -14,6 +14,7 @@ GEMMs go to the vendor library through torch (hipBLASLt/rocBLAS): plain library 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -34,6 +35,9 @@ class _LayerCache:
                              w2=c(m[1].ffn[3].weight), b2=c(m[1].ffn[3].bias), b1f=f(m[1].ffn[0].bias),
                              b2f=f(m[1].ffn[3].bias))
         self.ffn1, self.ffn2 = ffn(layer.ffn_module1), ffn(layer.ffn_module2)
+        if ops.ffn_supported(self.ffn1["w1"].shape[1], self.ffn1["w1"].shape[0], dtype) and self.ffn1["w1"].is_cuda:
+            for q in (self.ffn1, self.ffn2):                       # cm_ffn_fused's fragment-tiled weight images
+                q["w1p"], q["w2p"] = ops.PackedWeight(q["w1"]), ops.PackedWeight(q["w2"])
         self.norm1 = (f(layer.norm1.norm.weight), f(layer.norm1.norm.bias), layer.norm1.norm.eps)
         self.norm2 = (f(layer.norm2.norm.weight), f(layer.norm2.norm.bias), layer.norm2.norm.eps)
         m = layer.mamba
@@ -64,6 +68,7 @@ class _LayerCache:
         self.in_bias_f = None if m.in_proj.bias is None else f(m.in_proj.bias)
         self.out_bias_f = None if m.out_proj.bias is None else f(m.out_proj.bias)
         self.dw_w, self.dw_b = f(cm.conv.weight), f(cm.conv.bias)
+        self.dw_wt = self.dw_w.reshape(self.dw_w.shape[0], -1).t().contiguous()              # (k, D) taps, coalesced reads
         self.cm_ln2 = (f(cm.after_conv[0].weight), f(cm.after_conv[0].bias), cm.after_conv[0].eps)
         self.lin_w, self.lin_b = c(cm.after_conv[2].weight), c(cm.after_conv[2].bias)
         self.kernel_size = cm.kernel_size
@@ -146,18 +151,46 @@ def bimamba_fused(c: _LayerCache, h, batch, seqlen):
     return y
 
 
+# cm_ffn_fused: the whole feed-forward module (LayerNorm, both Linears, GELU, scaled residual, the next LayerNorm) in
+# one kernel with the hidden activations kept in LDS.  bf16 compute, d_model 256.  CM_FUSED_FFN=0 falls back to the
+# library GEMMs + cm_add_layernorm seams.
+USE_FUSED_FFN = os.environ.get("CM_FUSED_FFN", "1") == "1"
+
+
+def _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln=None):
+    """layer_forward with both feed-forward modules on cm_ffn_fused (bf16, d_model 256)."""
+    D = x.shape[-1]
+    f1, f2 = c.ffn1, c.ffn2
+    _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)   # x += 0.5 ffn1 ; norm1
+    y = bimamba_fused(c, h, batch, seqlen)
+    _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)              # x += mamba ; conv-module LN
+    pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)
+    g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
+    y = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
+    # x = norm2(x + conv + 0.5 ffn2(x + conv)); the encoder's final norm rides along on the last layer
+    if final_ln is not None:
+        _, out = ops.ffn_fused(x, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=y.view(-1, D),
+                               norm1=c.norm2, norm2=final_ln, h_dtype=torch.float32)
+        return out, None
+    ops.ffn_fused(x, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=y.view(-1, D), norm1=c.norm2,
+                  want_h=False)
+    return x, None
+
+
 def layer_forward(layer, x, batch, seqlen, dtype, next_ln=None, final_ln=None):
     """One ConmambaEncoderLayer on the fp32 residual stream x (rows, D), in place.
     Returns (x, h) where h = next_ln(x) in the compute dtype if next_ln is given."""
     c = _cache(layer, dtype)
     D = x.shape[-1]
+    if USE_FUSED_FFN and ops.ffn_supported(D, c.ffn1["w1"].shape[0], dtype) and c.ffn2["w1"].shape[0] == c.ffn1["w1"].shape[0]:
+        return _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln)
     _, h = ops.add_layernorm(x, None, norm2=c.ffn1["ln"], out_dtype=dtype)                   # LN of ffn_module1
     y = _ffn(x, h, c.ffn1, dtype)
     _, h = ops.add_layernorm(x, y, 0.5, x_out=x, norm2=c.norm1, out_dtype=dtype)              # x += 0.5 ffn1 ; norm1
     y = bimamba_fused(c, h, batch, seqlen)
     _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)              # x += mamba ; conv-module LN
     pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)                       # pointwise conv D -> 2D
-    g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2])
+    g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
     y = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
     _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.ffn2["ln"], out_dtype=dtype)         # x += conv ; LN of ffn_module2
     y = _ffn(x, h, c.ffn2, dtype)
@@ -171,7 +204,6 @@ def layer_forward(layer, x, batch, seqlen, dtype, next_ln=None, final_ln=None):
     return x, None
 
 
-import os
 
 # cm_gemm_bf16 (hand-written MFMA GEMM with fused bias/GELU/residual+LayerNorm epilogues) is correct but, in round 1,
 # 2-3x slower than the vendor library on these shapes (profiles/r01/bench_ops_gemm.log): opt-in until it is tuned.
@@ -205,7 +237,7 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
     ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
     h = g(ycat.view(rows, 2 * E), c.out_cat, c.out_bias_f, epilogue=2, x=x, alpha=1.0, norm2=c.cm_ln)   # x += mixer
     pw = g(h, c.pw_w, c.pw_bf, epilogue=0).view(batch, seqlen, 2 * D)
-    gl = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2])
+    gl = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
     h = g(gl.view(rows, D), c.lin_w, c.lin_bf, epilogue=2, x=x, alpha=1.0, norm2=c.ffn2["ln"])           # x += conv
     u2 = g(h, c.ffn2["w1"], c.ffn2["b1f"], epilogue=1)
     return g(u2, c.ffn2["w2"], c.ffn2["b2f"], epilogue=2, x=x, alpha=0.5, norm1=c.norm2, norm2=next_ln,
@@ -270,7 +302,8 @@ def _frontend_cache(model, dtype):
         lin = model.Transformer.custom_src_module.layers[0].w
         c = dict(dtype=dtype, ver=ver,
                  w2=b1.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last),
-                 b2=b1.conv.bias.detach().to(dtype),
+                 b2=b1.conv.bias.detach().to(dtype), b2f=b1.conv.bias.detach().float().contiguous(),
+                 w2_ohwi=b1.conv.weight.detach().to(dtype).permute(0, 2, 3, 1).contiguous(),
                  ln2=(b1.norm.norm.weight.detach().float().reshape(-1).contiguous(),
                       b1.norm.norm.bias.detach().float().reshape(-1).contiguous(), b1.norm.norm.eps),
                  lin_w=lin.weight.detach().to(dtype).contiguous(), lin_b=lin.bias.detach().to(dtype))
@@ -293,6 +326,11 @@ def asr_encode(model, wavs, wav_lens, dtype: Optional[torch.dtype] = None):
         b0 = model.CNN.blocks[0]
         y1 = ops.cnn_block1(feats, b0.conv.weight, b0.conv.bias, b0.norm.norm.weight, b0.norm.norm.bias,
                             b0.norm.norm.eps, 0.01, out_dtype=dtype, pad_out=1)     # (B, T1+2, F1+2, 64) NHWC
+        if dtype == torch.bfloat16 and tuple(c["w2_ohwi"].shape) == (32, 3, 3, 64):
+            src = ops.cnn_block2(y1, c["w2_ohwi"], c["b2f"], c["ln2"][0], c["ln2"][1], c["ln2"][2], 0.01)   # (B, T2, 640)
+            batch, t2 = src.shape[0], src.shape[1]
+            x = torch.addmm(c["lin_b"], src.view(batch * t2, -1), c["lin_w"].t())
+            return encoder_forward(model.Transformer.encoder, x.view(batch, t2, -1), dtype)
         y2 = F.conv2d(y1.permute(0, 3, 1, 2), c["w2"], c["b2"], stride=2)           # channels_last in / out
         y2 = y2.permute(0, 2, 3, 1)                                                 # (B, T2, F2, 32)
         if not y2.is_contiguous():

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as ct
 from typing import Optional, Tuple
 
+import os
 import torch
 
 from . import _native as N
@@ -338,9 +339,10 @@ def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_
     return x_out, out
 
 
-def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5):
+def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None):
     """(batch, seqlen, 2*dim) -> (batch, seqlen, dim): GLU, depthwise conv (k=31, same padding), LayerNorm, GELU
-    (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k)."""
+    (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k); weight_t: optional precomputed fp32 (k, dim) copy of the
+    taps (made here per call otherwise) so that the kernel's per-channel tap reads are coalesced."""
     _dev_check(inp, weight, bias, ln_weight, ln_bias)
     if not inp.is_contiguous():
         inp = inp.contiguous()
@@ -352,6 +354,10 @@ def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5):
     a = N.GluDwconvArgs()
     a.batch, a.seqlen, a.dim, a.ksize, a.io_dtype = b, l, d, w.shape[1], _DT[inp.dtype]
     a.in_, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.out = _ptr(inp), _ptr(w), _ptr(bs), _ptr(g), _ptr(bt), float(eps), _ptr(out)
+    wt = w.t().contiguous() if weight_t is None else weight_t
+    if wt.dtype != torch.float32 or wt.shape != (w.shape[1], d) or not wt.is_contiguous():
+        raise RuntimeError("glu_dwconv_ln_gelu: weight_t must be a contiguous fp32 (k, dim) tensor")
+    a.weight_t = _ptr(wt)
     a.stream = _stream()
     _launch("cm_glu_dwconv_ln_gelu", N.lib().cm_glu_dwconv_ln_gelu, a, units=b * l)
     return out
@@ -373,6 +379,33 @@ def cnn_block1(feats, weight, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01, ou
                                                                           float(eps), float(slope), _ptr(out))
     a.stream = _stream()
     _launch("cm_cnn_block1", N.lib().cm_cnn_block1, a, units=b * t)
+    return out
+
+
+def cnn_block2(y1, weight_ohwi, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01):
+    """y1 (batch, T_in, F_in, 64) bf16 channels-last (cnn_block1 output with its reflect border) ->
+    (batch, T2, F2*32) bf16: 3x3 stride-2 conv 64 -> 32, LayerNorm over (freq, channel), LeakyReLU (cm_cnn_block2).
+    weight_ohwi: (32, 3, 3, 64) bf16 contiguous (a Conv2d weight permuted to output, row, column, input)."""
+    _dev_check(y1, weight_ohwi, bias, ln_weight, ln_bias)
+    if y1.dtype != torch.bfloat16 or not y1.is_contiguous() or y1.dim() != 4:
+        raise RuntimeError("cnn_block2: input must be a contiguous bf16 (batch, T, F, C) tensor")
+    if weight_ohwi.dtype != torch.bfloat16 or not weight_ohwi.is_contiguous() or weight_ohwi.dim() != 4:
+        raise RuntimeError("cnn_block2: weight must be a contiguous bf16 (C_out, 3, 3, C_in) tensor")
+    b, t, f, cin = y1.shape
+    cout = weight_ohwi.shape[0]
+    if tuple(weight_ohwi.shape[1:]) != (3, 3, cin):
+        raise RuntimeError("cnn_block2: weight shape does not match the input channels / 3x3 taps")
+    t2, f2 = (t - 3) // 2 + 1, (f - 3) // 2 + 1
+    bs, g, bt = _f32c(bias), _f32c(ln_weight).reshape(-1), _f32c(ln_bias).reshape(-1)
+    if g.numel() != f2 * cout or bt.numel() != f2 * cout:
+        raise RuntimeError("cnn_block2: LayerNorm parameters must have F2 * C_out elements")
+    out = torch.empty((b, t2, f2 * cout), dtype=torch.bfloat16, device=y1.device)
+    a = N.CnnBlock2Args()
+    a.batch, a.T_in, a.F_in, a.C_in, a.C_out = b, t, f, cin, cout
+    a.in_, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.slope, a.out = (_ptr(y1), _ptr(weight_ohwi), _ptr(bs), _ptr(g), _ptr(bt),
+                                                                      float(eps), float(slope), _ptr(out))
+    a.stream = _stream()
+    _launch("cm_cnn_block2", N.lib().cm_cnn_block2, a, units=b * t2)
     return out
 
 
@@ -409,6 +442,67 @@ def gemm_bf16(a, w, bias=None, epilogue=0, x=None, alpha=1.0, norm1=None, norm2=
     return out
 
 
+def ffn_supported(d_model: int, hidden: int, dtype) -> bool:
+    return dtype == torch.bfloat16 and d_model == 256 and hidden >= 256 and hidden % 256 == 0
+
+
+class PackedWeight:
+    """A bf16 (rows, cols) matrix in cm_ffn_fused's fragment-tiled layout (cm_ffn_pack_weights)."""
+
+    def __init__(self, w: torch.Tensor):
+        _dev_check(w)
+        if w.dtype != torch.bfloat16 or w.dim() != 2:
+            raise RuntimeError("PackedWeight: expected a 2-D bf16 tensor")
+        w = w.contiguous()
+        self.shape = tuple(w.shape)
+        self.data = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+        rc = N.lib().cm_ffn_pack_weights(_ptr(w), w.shape[0], w.shape[1], _ptr(self.data), _stream())
+        N.check(rc, "cm_ffn_pack_weights")
+
+
+def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0, norm1=None, norm2=None,
+              x_out=None, want_h=True, h_dtype=torch.bfloat16):
+    """Whole feed-forward module on the fp32 residual stream (cm_ffn_fused):
+        xin = x + add_scale*addend;  r = xin + alpha*(W2 gelu(W1 LN_pre(xin) + b1) + b2);  r = LN1(r) if norm1;
+        x_out <- r (x itself when x_out is None);  returns h = LN2(r) (or r when norm2 is None) in h_dtype if want_h.
+    x (rows, 256) fp32; w1 (hidden, 256) / w2 (256, hidden) bf16 tensors or PackedWeight (pack once, reuse); b1/b2 and
+    LayerNorm parameters fp32; addend (rows, 256) bf16; norm = (weight, bias, eps)."""
+    _dev_check(x, b1, b2, addend)
+    rows, d = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("ffn_fused: x must be a contiguous fp32 (rows, 256) tensor")
+    if d != 256:
+        raise RuntimeError(f"ffn_fused: d_model must be 256 (got {d})")
+    w1 = w1 if isinstance(w1, PackedWeight) else PackedWeight(w1)
+    w2 = w2 if isinstance(w2, PackedWeight) else PackedWeight(w2)
+    if w1.shape[1] != d or w2.shape != (d, w1.shape[0]):
+        raise RuntimeError("ffn_fused: weight shapes do not match x")
+    for t in (b1, b2) + tuple(pre_norm[:2]):
+        if t.dtype != torch.float32:
+            raise RuntimeError("ffn_fused: biases and LayerNorm parameters must be fp32")
+    a = N.FfnArgs()
+    a.rows, a.dim, a.hidden = rows, d, w1.shape[0]
+    a.x, a.pre_g, a.pre_b, a.pre_eps = _ptr(x), _ptr(pre_norm[0]), _ptr(pre_norm[1]), float(pre_norm[2])
+    a.w1, a.b1, a.w2, a.b2, a.alpha = _ptr(w1.data), _ptr(b1), _ptr(w2.data), _ptr(b2), float(alpha)
+    if addend is not None:
+        if addend.dtype != torch.bfloat16 or not addend.is_contiguous() or addend.shape != x.shape:
+            raise RuntimeError("ffn_fused: addend must be a contiguous bf16 tensor shaped like x")
+        a.addend, a.add_scale = _ptr(addend), float(add_scale)
+    if norm1 is not None:
+        a.n1_g, a.n1_b, a.n1_eps = _ptr(norm1[0]), _ptr(norm1[1]), float(norm1[2])
+    if norm2 is not None:
+        a.n2_g, a.n2_b, a.n2_eps = _ptr(norm2[0]), _ptr(norm2[1]), float(norm2[2])
+    xo = x if x_out is None else x_out
+    a.x_out = _ptr(xo)
+    h = None
+    if want_h:
+        h = torch.empty((rows, d), dtype=h_dtype, device=x.device)
+        a.h_out, a.h_dtype = _ptr(h), _DT[h_dtype]
+    a.stream = _stream()
+    _launch("cm_ffn_fused", N.lib().cm_ffn_fused, a, units=rows)
+    return xo, h
+
+
 _BANDS = {}
 
 
@@ -421,7 +515,16 @@ def _mel_bands(fb: torch.Tensor):
         lo = torch.where(nz, idx, fb.shape[0]).amin(0).to(torch.int32)
         hi = (torch.where(nz, idx, -1).amax(0) + 1).to(torch.int32)
         lo = torch.minimum(lo, hi)
-        _BANDS[key] = (lo.contiguous(), hi.contiguous())
+        width = (hi - lo).to(torch.int64)
+        off = torch.zeros(fb.shape[1] + 1, dtype=torch.int64, device=fb.device)
+        off[1:] = torch.cumsum(width, 0)
+        total = int(off[-1])
+        packed = None
+        if 0 < total <= 4096:                              # gather each filter's band into one packed vector
+            m_of = torch.repeat_interleave(torch.arange(fb.shape[1], device=fb.device), width)
+            f_of = torch.arange(total, device=fb.device) - off[m_of] + lo.to(torch.int64)[m_of]
+            packed = fb[f_of, m_of].contiguous()
+        _BANDS[key] = (lo.contiguous(), hi.contiguous(), off.to(torch.int32).contiguous(), packed)
     return _BANDS[key]
 
 
@@ -442,8 +545,10 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     a.spec, a.fbank, a.db, a.umax, a.amin, a.top_db = _ptr(sr), _ptr(fb), _ptr(db), _ptr(umax), float(amin), float(top_db)
     mean, std = _f32c(mean), _f32c(std)
     a.mean, a.std = _ptr(mean), _ptr(std)
-    lo, hi = _mel_bands(fb)
+    lo, hi, off, packed = _mel_bands(fb)
     a.band_lo, a.band_hi = _ptr(lo), _ptr(hi)
+    if packed is not None:
+        a.band_off, a.band_w = _ptr(off), _ptr(packed)
     a.spec_bs, a.spec_fs, a.spec_ts = sr.stride(0) // 2, sr.stride(1) // 2, sr.stride(2) // 2
     a.stream = _stream()
     _launch("cm_fbank_mel_db", N.lib().cm_fbank_mel_db, a, units=b * t)

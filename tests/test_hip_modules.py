@@ -199,6 +199,100 @@ def test_fused_frontend_and_encoder_match_unfused_and_oracle(dtype):
         torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)
 
 
+@pytest.mark.parametrize("rows,hidden,addend,n1,n2,hdt", [
+    (64, 256, False, False, True, torch.bfloat16),
+    (1000, 1024, False, False, True, torch.bfloat16),      # ragged last tile, FFN 1 of a layer (h = norm1)
+    (333, 1024, True, True, False, None),                  # FFN 2 of a layer: addend, closing norm2, no h
+    (130, 512, True, True, True, torch.float32),           # last layer: + the encoder's final norm, fp32 out
+])
+def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt):
+    """cm_ffn_fused vs an fp32 restatement with the kernel's rounding points (bf16 GEMM operands, fp32 accumulate)."""
+    from mamba_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + hidden)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale)
+    x = rn(rows, 256, scale=2.0) + 0.5
+    add = rn(rows, 256).bfloat16() if addend else None
+    w1, b1 = rn(hidden, 256, scale=256 ** -0.5).bfloat16(), rn(hidden, scale=0.1)
+    w2, b2 = rn(256, hidden, scale=hidden ** -0.5).bfloat16(), rn(256, scale=0.1)
+    ln = lambda: (1.0 + 0.1 * rn(256), 0.1 * rn(256), 1e-5)
+    pre, nn1, nn2 = ln(), (ln() if n1 else None), (ln() if n2 else None)
+    # reference
+    xin = x + (0.7 * add.float() if addend else 0.0)
+    LN = lambda t, p_: torch.nn.functional.layer_norm(t, (256,), p_[0], p_[1], p_[2])
+    hn = LN(xin, pre).bfloat16().float()
+    hid = torch.nn.functional.gelu(hn @ w1.float().t() + b1).bfloat16().float()
+    r = xin + 0.5 * (hid @ w2.float().t() + b2)
+    if n1:
+        r = LN(r, nn1)
+    want_h = None if hdt is None else (LN(r, nn2) if n2 else r)
+    # kernel
+    d = lambda t: None if t is None else t.to(DEV)
+    dn = lambda p_: None if p_ is None else (p_[0].to(DEV), p_[1].to(DEV), p_[2])
+    xg = x.to(DEV)
+    xo, h = ops.ffn_fused(xg, dn(pre), d(w1), d(b1), d(w2), d(b2), alpha=0.5, addend=d(add), add_scale=0.7, norm1=dn(nn1),
+                          norm2=dn(nn2), want_h=hdt is not None, h_dtype=hdt or torch.bfloat16)
+    assert xo.data_ptr() == xg.data_ptr()
+    torch.testing.assert_close(xo.cpu(), r, rtol=2e-3, atol=4e-3)
+    assert (xo.cpu() - r).abs().mean() < 3e-4
+    if hdt is not None:
+        assert h.dtype == hdt
+        tol = dict(rtol=2e-3, atol=4e-3) if hdt == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+        torch.testing.assert_close(h.float().cpu(), want_h, **tol)
+
+
+@pytest.mark.parametrize("batch,t_in,f_in", [(2, 42, 42), (3, 37, 42), (1, 9, 22), (2, 11, 9)])
+def test_cnn_block2_kernel(batch, t_in, f_in):
+    """cm_cnn_block2 (implicit-GEMM conv 64->32 3x3 s2 + LayerNorm + LeakyReLU) vs torch conv2d/layer_norm in fp32 on the
+    same bf16-rounded operands; ragged last tiles and frequency widths that do not fill a 16-position MFMA tile."""
+    from mamba_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(batch * 100 + t_in)
+    y1 = torch.randn(batch, t_in, f_in, 64, generator=g).bfloat16()
+    w = (torch.randn(32, 64, 3, 3, generator=g) * (64 * 9) ** -0.5).bfloat16()
+    bias = torch.randn(32, generator=g) * 0.1
+    t2, f2 = (t_in - 3) // 2 + 1, (f_in - 3) // 2 + 1
+    ln_g, ln_b = 1.0 + 0.1 * torch.randn(f2, 32, generator=g), 0.1 * torch.randn(f2, 32, generator=g)
+    ref = torch.nn.functional.conv2d(y1.float().permute(0, 3, 1, 2), w.float(), bias, stride=2).permute(0, 2, 3, 1)
+    ref = torch.nn.functional.layer_norm(ref.reshape(batch, t2, f2 * 32), (f2 * 32,), ln_g.reshape(-1), ln_b.reshape(-1), 1e-5)
+    ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    got = ops.cnn_block2(y1.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV), ln_g.to(DEV), ln_b.to(DEV), 1e-5, 0.01)
+    assert got.shape == (batch, t2, f2 * 32) and got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    assert (got.float().cpu() - ref).abs().mean() < 2e-3
+
+
+def test_ffn_fused_rejects_unsupported():
+    from mamba_asr_amd import ops
+    x = torch.zeros(8, 128, device=DEV)
+    w1 = torch.zeros(256, 128, device=DEV, dtype=torch.bfloat16)
+    w2 = torch.zeros(128, 256, device=DEV, dtype=torch.bfloat16)
+    v = lambda n: torch.zeros(n, device=DEV)
+    with pytest.raises(RuntimeError, match="d_model must be 256"):
+        ops.ffn_fused(x, (v(128), v(128), 1e-5), w1, v(256), w2, v(128))
+
+
+def test_fused_ffn_layer_path_matches_library_path(monkeypatch):
+    """Encoder forward with the feed-forward modules on cm_ffn_fused == the library-GEMM fused path and the fp32 path."""
+    from mamba_asr_amd import fused
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    torch.manual_seed(5)
+    enc = ConmambaEncoder(num_layers=3, d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True,
+                          dropout=0.0, causal=False, mamba_config=dict(CFG)).to(DEV).eval()
+    for p in enc.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_normal_(p)
+    x = torch.randn(3, 90, 256, device=DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "USE_FUSED_FFN", False)
+        ref = fused.encoder_forward(enc, x, dtype=torch.bfloat16)
+        ref32 = fused.encoder_forward(enc, x, dtype=torch.float32)
+        monkeypatch.setattr(fused, "USE_FUSED_FFN", True)
+        got = fused.encoder_forward(enc, x, dtype=torch.bfloat16)
+    torch.testing.assert_close(got.cpu(), ref32.cpu(), rtol=3e-2, atol=5e-2)
+    torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=3e-2, atol=5e-2)
+    # the fused path rounds less (no bf16 FFN output): it must not be further from fp32 than the library path
+    assert (got - ref32).abs().mean() <= 1.2 * (ref - ref32).abs().mean()
+
+
 def test_native_gemm_layer_path_matches_library_path(monkeypatch):
     """Encoder forward with every projection on cm_gemm_bf16 (fused epilogues) == the library-GEMM fused path."""
     from mamba_asr_amd import fused
