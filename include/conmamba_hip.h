@@ -411,6 +411,9 @@ typedef struct cm_fbank_args {
                                            contiguous (batch, n_freq, frames).  torch.stft hands out a transposed view
                                            of a (batch, frames, n_freq) buffer: passing its strides avoids a 260 MB copy */
     void *stream;
+    float *umax_part;            /* optional (batch, ceil(frames / 16)) scratch: cm_fbank_mel_db stores per-tile maxima
+                                    there instead of issuing atomics on umax, and cm_fbank_finish reduces them into
+                                    umax; pass the same args to both calls */
 } cm_fbank_args;
 
 int cm_fbank_mel_db(const cm_fbank_args *args);

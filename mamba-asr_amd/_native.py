@@ -137,7 +137,7 @@ class FbankArgs(C.Structure):
         ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
         ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
         ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("band_off", vp), ("band_w", fp), ("spec_bs", i64), ("spec_fs", i64), ("spec_ts", i64),
-        ("stream", vp),
+        ("stream", vp), ("umax_part", fp),
     ]
 
 

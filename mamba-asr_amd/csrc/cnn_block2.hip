@@ -64,18 +64,37 @@ __global__ __launch_bounds__(512) void cnn_block2_kernel(const cm_cnn_block2_arg
     const int pr = pidx / F2, pf = pidx % F2;
     const uint16_t *frag0 = rows + ((size_t)(2 * pr) * F1p + 2 * pf) * CS + lq * 8;
 
+    // The input rows of a tile travel global -> registers -> LDS; the registers of tile i+1 are loaded while tile i is
+    // computed (a first version loaded and stored piece by piece and spent 17 us per tile on exposed HBM latency).
+    constexpr int MAXP = 12;                                      // 16-byte pieces per thread per tile (host-checked)
+    const int pieces_per_row = F1p * 8, npieces = nrows * pieces_per_row;
+    uint4 pre[MAXP];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_utt, r0 = (tile % tiles_per_utt) * TT;
+        const uint16_t *src = in + (int64_t)b * T1p * F1p * CIN;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = tid + k * nthreads;
+            if (i < npieces) {
+                const int row = i / pieces_per_row, rem = i - row * pieces_per_row;
+                const int tr = min(2 * r0 + row, T1p - 1);
+                pre[k] = *reinterpret_cast<const uint4 *>(src + ((int64_t)tr * F1p + (rem >> 3)) * CIN + (rem & 7) * 8);
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_utt, r0 = (tile % tiles_per_utt) * TT;
-        // ---- stage the input rows 2*r0 .. 2*r0 + 2*TT (clamped at the end of the utterance)
-        const uint16_t *src = in + (int64_t)b * T1p * F1p * CIN;
-        const int pieces_per_row = F1p * 8;
-        for (int i = tid; i < nrows * pieces_per_row; i += nthreads) {
-            const int row = i / pieces_per_row, rem = i - row * pieces_per_row;
-            const int col = rem >> 3, pc = rem & 7;
-            const int tr = min(2 * r0 + row, T1p - 1);
-            *reinterpret_cast<uint4 *>(rows + ((size_t)row * F1p + col) * CS + pc * 8) =
-                *reinterpret_cast<const uint4 *>(src + ((int64_t)tr * F1p + col) * CIN + pc * 8);
+        // ---- input rows 2*r0 .. 2*r0 + 2*TT (clamped at the end of the utterance) -> LDS
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = tid + k * nthreads;
+            if (i < npieces) {
+                const int row = i / pieces_per_row, rem = i - row * pieces_per_row;
+                *reinterpret_cast<uint4 *>(rows + ((size_t)row * F1p + (rem >> 3)) * CS + (rem & 7) * 8) = pre[k];
+            }
         }
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
         // ---- implicit GEMM: 16 positions x 32 channels per wave
         if (wave < NB) {
@@ -147,6 +166,7 @@ extern "C" int cm_cnn_block2(const cm_cnn_block2_args *args) {
     if (nwaves > 8) nwaves = 8;
     const size_t smem = (size_t)(2 * TT + 1) * a.F_in * CS * 2 + (size_t)NB * 16 * OTS * 4;
     CM_REQUIRE(smem <= 150 * 1024, CM_EUNSUPPORTED, "cnn_block2: F_in %d needs %zu bytes of LDS", a.F_in, smem);
+    CM_REQUIRE((2 * TT + 1) * a.F_in * 8 <= 12 * 64 * nwaves, CM_EUNSUPPORTED, "cnn_block2: F_in %d too wide for the row prefetch", a.F_in);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_block2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -58,24 +58,51 @@ __global__ __launch_bounds__(256) void fbank_mel_db_kernel(const cm_fbank_args p
         p.db[((int64_t)b * T + t0 + j) * M + m] = db;
         local_max = fmaxf(local_max, db);
     }
-    // per-utterance maximum: wave reduce, one atomic per wave (float max via the int ordering trick)
+    // per-tile maximum: wave reduce, then the four waves through LDS.  With umax_part the tile maximum is stored (no
+    // atomics: 32k same-address float atomics cost more than the rest of this kernel, 208 of 379 us at 32 x 4000 frames)
+    // and cm_fbank_finish reduces the tiles of an utterance; without it, one atomic per workgroup.
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off, 64));
-    if ((threadIdx.x & 63) == 0 && local_max > -INFINITY) {
-        int *addr = reinterpret_cast<int *>(p.umax + b);
-        if (local_max >= 0.f) atomicMax(addr, __float_as_int(local_max));
-        else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(local_max));
+    __syncthreads();                                              // pw is dead: reuse its first floats
+    if ((threadIdx.x & 63) == 0) pw[threadIdx.x >> 6] = local_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mx = fmaxf(fmaxf(pw[0], pw[1]), fmaxf(pw[2], pw[3]));
+        if (p.umax_part) {
+            p.umax_part[(int64_t)b * gridDim.x + blockIdx.x] = mx;
+        } else if (mx > -INFINITY) {
+            int *addr = reinterpret_cast<int *>(p.umax + b);
+            if (mx >= 0.f) atomicMax(addr, __float_as_int(mx));
+            else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(mx));
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void fbank_finish_kernel(const cm_fbank_args p) {
-    const int64_t n = (int64_t)p.batch * p.frames * p.n_mels;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i % p.n_mels);
-        const int b = (int)(i / ((int64_t)p.frames * p.n_mels));
-        float v = fmaxf(p.db[i], p.umax[b] - p.top_db);
-        if (p.mean) v = (v - p.mean[m]) / p.std[m];
-        p.db[i] = v;
+// grid (chunks, batch): a workgroup first reduces its utterance's tile maxima (when umax_part is given), then clamps and
+// normalises its slice of the utterance.
+__global__ __launch_bounds__(256) void fbank_finish_kernel(const cm_fbank_args p, int ntiles) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    float um;
+    if (p.umax_part) {
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < ntiles; i += blockDim.x) mx = fmaxf(mx, p.umax_part[(int64_t)b * ntiles + i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        um = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.umax[b] = um;
+    } else {
+        um = p.umax[b];
+    }
+    const float floor_db = um - p.top_db;
+    const int64_t per_utt = (int64_t)p.frames * p.n_mels;
+    float *db = p.db + (int64_t)b * per_utt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_utt; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = fmaxf(db[i], floor_db);
+        if (p.mean) { const int m = (int)(i % p.n_mels); v = (v - p.mean[m]) / p.std[m]; }
+        db[i] = v;
     }
 }
 
@@ -115,10 +142,12 @@ extern "C" int cm_fbank_finish(const cm_fbank_args *args) {
     const cm_fbank_args &a = *args;
     CM_REQUIRE(a.batch > 0 && a.frames > 0 && a.n_mels > 0 && a.db && a.umax, CM_EINVAL, "fbank_finish: bad sizes or NULL tensor");
     CM_REQUIRE(!a.mean || a.std, CM_EINVAL, "fbank_finish: mean without std");
-    const int64_t n = (int64_t)a.batch * a.frames * a.n_mels;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fbank_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a);
+    CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "fbank_finish: batch %d exceeds the grid limit", a.batch);
+    const int64_t per_utt = (int64_t)a.frames * a.n_mels;
+    int64_t chunks = (per_utt + 256 * 8 - 1) / (256 * 8);
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(fbank_finish_kernel, dim3((unsigned)chunks, a.batch), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a,
+                       (a.frames + FT - 1) / FT);
     return cm_launch_status("cm_fbank_finish");
 }
 

@@ -402,6 +402,7 @@ int by_split(const cm_scan_cl_args &a, int ns) {
 int cm_scan_split_override();
 
 extern "C" int cm_debug_set(int v) { return g_debug.exchange(v); }
+extern "C" int cm_debug_get() { return g_debug.load(); }
 extern "C" int cm_debug_read_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
 }

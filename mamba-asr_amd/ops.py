@@ -539,7 +539,8 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     fb = _f32c(fbank)
     m = fb.shape[1]
     db = torch.empty((b, t, m), dtype=torch.float32, device=sr.device)
-    umax = torch.full((b,), float("-inf"), dtype=torch.float32, device=sr.device)
+    umax = torch.empty((b,), dtype=torch.float32, device=sr.device)
+    part = torch.empty((b, (t + 15) // 16), dtype=torch.float32, device=sr.device)      # per-tile maxima (no atomics)
     a = N.FbankArgs()
     a.batch, a.n_freq, a.frames, a.n_mels = b, nf, t, m
     a.spec, a.fbank, a.db, a.umax, a.amin, a.top_db = _ptr(sr), _ptr(fb), _ptr(db), _ptr(umax), float(amin), float(top_db)
@@ -550,6 +551,7 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     if packed is not None:
         a.band_off, a.band_w = _ptr(off), _ptr(packed)
     a.spec_bs, a.spec_fs, a.spec_ts = sr.stride(0) // 2, sr.stride(1) // 2, sr.stride(2) // 2
+    a.umax_part = _ptr(part)
     a.stream = _stream()
     _launch("cm_fbank_mel_db", N.lib().cm_fbank_mel_db, a, units=b * t)
     _launch("cm_fbank_finish", N.lib().cm_fbank_finish, a, units=b * t)
