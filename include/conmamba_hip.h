@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 1
+#define CM_ABI_VERSION 2
 
 /* error codes */
 #define CM_OK            0
@@ -187,6 +187,13 @@ typedef struct cm_scan_cl_dir {
     int64_t bc_ns, bc_bs;    /* state / batch strides of B and C                            */
     int32_t reverse_time;
     int32_t dt_rank;
+    const void *xdbl;        /* optional (batch, seqlen, 48) in the I/O dtype: the x_proj GEMM's output rows as it
+                                wrote them, columns [0,16) = dt features zero-padded to 16, [16,32) = B_t, [32,48) =
+                                C_t (selective_scan_interface.py:186, 192-215 without the transposed copies).  When
+                                set for every direction, B / C / dt_low / delta are ignored, dt_weight must be
+                                (dim, 16) fp32 zero-padded, dim a multiple of 8 (bf16) / 4 (fp32), and the row-group
+                                kernel (csrc/scan_rows_fwd.hip) runs                                                */
+    int64_t xdbl_bs, xdbl_ts;/* batch / step strides of xdbl in elements (multiples of 8 for bf16, 4 for fp32)       */
 } cm_scan_cl_dir;
 
 typedef struct cm_scan_cl_args {

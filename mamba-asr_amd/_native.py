@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libconmamba_hip.so")
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -59,6 +59,7 @@ class ScanClDir(C.Structure):
         ("delta_bias", fp), ("out", vp),
         ("u_bs", i64), ("u_ts", i64), ("delta_bs", i64), ("delta_ts", i64), ("out_bs", i64), ("out_ts", i64),
         ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("dt_rank", i32),
+        ("xdbl", vp), ("xdbl_bs", i64), ("xdbl_ts", i64),
     ]
 
 

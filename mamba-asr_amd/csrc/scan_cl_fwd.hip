@@ -400,6 +400,7 @@ int by_split(const cm_scan_cl_args &a, int ns) {
 }  // namespace
 
 int cm_scan_split_override();
+int cm_scan_rows_fwd(const cm_scan_cl_args &a);      // scan_rows_fwd.hip
 
 extern "C" int cm_debug_set(int v) { return g_debug.exchange(v); }
 extern "C" int cm_debug_get() { return g_debug.load(); }
@@ -414,6 +415,12 @@ extern "C" int cm_scan_cl_fwd(const cm_scan_cl_args *args) {
                a.batch, a.dim, a.seqlen);
     CM_REQUIRE(a.dstate == 16, CM_EUNSUPPORTED, "scan_cl_fwd: dstate %d unsupported (16 only)", a.dstate);
     CM_REQUIRE(a.ndir == 1 || a.ndir == 2, CM_EINVAL, "scan_cl_fwd: ndir must be 1 or 2");
+    {
+        int with_rows = 0;
+        for (int i = 0; i < a.ndir; ++i) with_rows += a.dir[i].xdbl != nullptr;
+        CM_REQUIRE(with_rows == 0 || with_rows == a.ndir, CM_EINVAL, "scan_cl_fwd: xdbl must be set for every direction or none");
+        if (with_rows) return cm_scan_rows_fwd(a);
+    }
     CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "scan_cl_fwd: batch %d exceeds the grid limit", a.batch);
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];

@@ -1,0 +1,304 @@
+// scan_rows_fwd.hip — channels-last selective scan forward, "row-group" variant (contract: cm_scan_cl_fwd with
+// cm_scan_cl_dir.xdbl set; reference semantics selective_scan_interface.py:91-157 + the dt_proj GEMM of :187).
+//
+// Why a second shape.  scan_cl_fwd.hip splits the 16 states of a channel over 8 WAVES: every step each wave reads
+// (delta', delta'*u) from LDS, writes a partial output to LDS, an "owner" wave sums 8 partials, and the workgroup
+// barriers every 8 steps — ~30 LDS instructions per wave per block and a barrier domain per CU set the pace.
+// Here the 16 states of a channel sit in 4 LANES of ONE wave (lane = channel%16 + 16*group, 4 states per lane), and the
+// otherwise idle matrix pipe does the cross-lane work in fp32:
+//   * y[t][c] = sum over the 4 lane groups of the per-lane partial sum_i C[t][4g+i] h_i is ONE v_mfma_f32_16x16x4_f32
+//     per step: A = one-hot row selector (row t), B = the partials (k = lane group, n = channel), accumulated over the 16
+//     steps of a block, so that afterwards lane (c, g) holds y for steps 4g..4g+3 of its channel;
+//   * delta[t][c] = W_dt[c,:] . dt[t,:] is four more MFMAs per 16-step block and lands in the SAME lane layout, so
+//     softplus, delta*u, the D skip and the SiLU gate are done exactly once per (channel, step), spread over all 64
+//     lanes, with no cross-wave exchange at all;
+//   * (delta', delta'*u) go from that layout to the recurrence layout through a 2.3 KB per-wave LDS patch (in-order LDS
+//     within a wave: no barrier); B_t/C_t come from the staged x_dbl tile with 16-byte broadcast reads;
+//   * the four waves of a workgroup (64 channels = one 128-byte row segment) only share the staged input tiles
+//     (u, z, x_dbl rows: 16 steps per tile, 3 tiles in flight, every thread one 16-byte global load per tensor), which
+//     costs ONE barrier per 16 steps, a block behind the loads.
+// x_dbl is read as the x_proj GEMM wrote it: rows (batch*time, [dt(16, zero padded) | B(16) | C(16)]) in the I/O dtype —
+// no transposed copy, no fp32 staging buffer.
+#include "cm_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TB = 16;        // steps per block (= MFMA M)
+constexpr int NBUF = 3;       // staged input tiles
+constexpr int XS = 52;        // floats per staged x_dbl row (48 + pad: conflict-free fragment reads)
+constexpr int PWS = 36;       // floats per channel in the per-wave (delta', delta'*u) patch (32 + pad)
+
+template <typename IO> struct rows_lds {
+    static constexpr int kTile = TB * 64 * (int)sizeof(IO);
+    static constexpr int kU = 0, kZ = NBUF * kTile, kX = 2 * NBUF * kTile;
+    static constexpr int kPw = kX + NBUF * TB * XS * 4;
+    static constexpr int kBytes = kPw + 4 * 16 * PWS * 4;
+};
+
+template <typename IO> __device__ __forceinline__ float ld_io(const IO *p) { return cm_elem<IO>::load(p); }
+
+__device__ __forceinline__ void unpack_store(float *dst, const uint4 v, float) {          // 4 fp32
+    *reinterpret_cast<uint4 *>(dst) = v;
+}
+__device__ __forceinline__ void unpack_store(float *dst, const uint4 v, cm_bf16) {        // 8 bf16 -> 8 fp32
+    *reinterpret_cast<f32x4 *>(dst) = f32x4{cm_bf16_lo(v.x), cm_bf16_hi(v.x), cm_bf16_lo(v.y), cm_bf16_hi(v.y)};
+    *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{cm_bf16_lo(v.z), cm_bf16_hi(v.z), cm_bf16_lo(v.w), cm_bf16_hi(v.w)};
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor over [base, base + bytes): loads past the end return 0 and stores past the end are dropped,
+// which is how the ragged last block (steps >= seqlen) is handled without per-row compares
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int64_t bytes) {
+    const int n = bytes > 0x7fffffff ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ void st_io(const __amdgpu_buffer_rsrc_t r, int voff, int soff, float v, cm_bf16) {
+    __builtin_amdgcn_raw_buffer_store_b16(cm_elem<cm_bf16>::to_bits(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void st_io(const __amdgpu_buffer_rsrc_t r, int voff, int soff, float v, float) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// FULL: z gate and softplus present (the BiMamba layer's call), resolved at compile time
+template <typename IO, bool REV, bool FULL>
+__device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, unsigned char *lds,
+                                          const int cx, const int b) {
+    using L = rows_lds<IO>;
+    constexpr int S = (int)sizeof(IO);
+    constexpr int VEC = cm_elem<IO>::kVec;       // elements per 16-byte vector
+    constexpr int CPR = 64 / VEC;                // 16-byte chunks per 64-channel row
+    constexpr int NCH = TB * CPR;                // chunks per (u or z) tile
+    constexpr int NV = 2 * NCH / 256;            // chunks per thread per block (u and z together)
+    constexpr int XCPR = 48 / VEC;               // chunks per x_dbl row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int T = p.seqlen, E = p.dim, c0 = cx * 64;
+    const int c = c0 + 16 * w + c16;
+    const bool c_ok = c < E;
+    const int cc = c_ok ? c : E - 1;
+    const bool has_z = FULL || p.z != nullptr;
+    const bool softplus = FULL || p.delta_softplus != 0;
+    const int nblk = (T + TB - 1) / TB;
+    const int u_ts = (int)d.u_ts, z_ts = (int)p.z_ts, x_ts = (int)d.xdbl_ts, o_ts = (int)d.out_ts;
+    const __amdgpu_buffer_rsrc_t ur = make_rsrc(reinterpret_cast<const IO *>(d.u) + (int64_t)b * d.u_bs, ((int64_t)(T - 1) * u_ts + E) * S);
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(has_z ? reinterpret_cast<const IO *>(p.z) + (int64_t)b * p.z_bs : nullptr,
+                                                has_z ? ((int64_t)(T - 1) * z_ts + E) * S : 0);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const IO *>(d.xdbl) + (int64_t)b * d.xdbl_bs, ((int64_t)(T - 1) * x_ts + 48) * S);
+    const __amdgpu_buffer_rsrc_t orr = make_rsrc(reinterpret_cast<IO *>(d.out) + (int64_t)b * d.out_bs, ((int64_t)(T - 1) * o_ts + E) * S);
+    const int tb0 = (REV ? nblk - 1 : 0) * TB;               // first block's base step; blocks advance by +-TB steps
+    constexpr int DIR = REV ? -1 : 1;
+
+    // ---- staging: global -> registers (issue) -> LDS (commit), one block of 16 steps at a time.
+    // Per-thread byte offsets into the batch slice advance by one block per issue (one add per tensor).
+    int uz_off[NV], uz_step[NV], uz_lds[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, tens = idx / NCH, within = idx % NCH;
+        const int ts = tens ? z_ts : u_ts;
+        uz_off[i] = ((tb0 + within / CPR) * ts + c0 + (within % CPR) * VEC) * S;
+        uz_step[i] = DIR * TB * ts * S;
+        uz_lds[i] = (tens ? L::kZ : L::kU) + within * 16;
+    }
+    const bool x_thread = tid < TB * XCPR;
+    int x_off = x_thread ? ((tb0 + tid / XCPR) * x_ts + (tid % XCPR) * VEC) * S : 0x7fffffff;
+    const int x_step = x_thread ? DIR * TB * x_ts * S : 0;
+    const int x_lds = L::kX + ((tid / XCPR) * XS + (tid % XCPR) * VEC) * 4;
+    u32x4 ruz[NV], rx;
+    auto issue = [&]() {                                          // next block in processing order
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int tens = (w * 64 + 256 * i) / NCH;                // wave-uniform (NCH is a multiple of 64)
+            ruz[i] = (tens == 0 || has_z) ? __builtin_amdgcn_raw_buffer_load_b128(tens ? zr : ur, uz_off[i], 0, 0) : u32x4{0u, 0u, 0u, 0u};
+            uz_off[i] += uz_step[i];
+        }
+        rx = __builtin_amdgcn_raw_buffer_load_b128(xr, x_off, 0, 0);
+        x_off += x_step;
+    };
+    auto commit = [&](const int buf_tile, const int buf_x) {      // byte offsets of the destination tiles
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4 *>(lds + uz_lds[i] + buf_tile) = ruz[i];
+        if (x_thread) unpack_store(reinterpret_cast<float *>(lds + x_lds + buf_x), uint4{rx[0], rx[1], rx[2], rx[3]}, IO{});
+    };
+
+    // ---- per-lane constants: 4 states of one channel
+    float Ap[4], Wdt[4], h[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float4 a4 = *reinterpret_cast<const float4 *>(d.A + (int64_t)cc * 16 + 4 * g);
+        Ap[0] = a4.x * CM_LOG2E; Ap[1] = a4.y * CM_LOG2E; Ap[2] = a4.z * CM_LOG2E; Ap[3] = a4.w * CM_LOG2E;
+        // B operand of the delta MFMAs: lane (n = channel, k = lane group) holds W_dt[c][4k + q], q = 0..3
+        const float4 w4 = *reinterpret_cast<const float4 *>(d.dt_weight + (int64_t)cc * 16 + 4 * g);
+        Wdt[0] = w4.x; Wdt[1] = w4.y; Wdt[2] = w4.z; Wdt[3] = w4.w;
+    }
+    const float bias = d.delta_bias ? d.delta_bias[cc] : 0.f;
+    const float Dv = d.D ? d.D[cc] : 0.f;
+    float sel[TB];                                                // A operands of the output MFMAs: one-hot rows
+#pragma unroll
+    for (int j = 0; j < TB; ++j) sel[j] = c16 == j ? 1.f : 0.f;
+    float uq[4], zq[4];                                           // (u, z) of the lane's 4 owned steps of the staged block
+    float *pww = reinterpret_cast<float *>(lds + L::kPw) + (w * 16 + c16) * PWS;
+    int o_off = c_ok ? ((tb0 + 4 * g) * o_ts + c) * S : 0x7fffffff;   // out-of-range offset: stores dropped
+    const int o_step = c_ok ? DIR * TB * o_ts * S : 0;
+
+    // delta' = softplus(W_dt . dt + bias), delta'*u for the block staged at (buf_tile, buf_x) -> per-wave patch;
+    // owned (u, z) -> registers.  tb = the block's base step.
+    auto produce = [&](const int buf_tile, const int buf_x, const int tb) {
+        const float *xt = reinterpret_cast<const float *>(lds + L::kX + buf_x);
+        // A operand: lane (m = step = lane%16, k = lane/16) holds dt[step][4k + q]
+        const f32x4 dtf = *reinterpret_cast<const f32x4 *>(xt + c16 * XS + 4 * g);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[0], Wdt[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[1], Wdt[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[2], Wdt[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[3], Wdt[3], acc, 0, 0, 0);
+        // acc[i] = delta_raw[step 4g+i][channel c16]
+        const IO *ut = reinterpret_cast<const IO *>(lds + L::kU + buf_tile) + 16 * w + c16 + 4 * g * 64;
+        const IO *zt = reinterpret_cast<const IO *>(lds + L::kZ + buf_tile) + 16 * w + c16 + 4 * g * 64;
+        const bool ragged = tb + TB > T;                          // uniform: only the last block of the sequence
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float dv = acc[i] + bias;
+            if (softplus) dv = cm_softplus(dv);
+            if (ragged) dv = tb + 4 * g + i < T ? dv : 0.f;       // padded steps: a = 1, b = 0 (state passes through)
+            const float uv = ld_io(ut + i * 64);
+            uq[i] = uv;
+            zq[i] = has_z ? ld_io(zt + i * 64) : 0.f;
+            o[2 * i] = dv;
+            o[2 * i + 1] = dv * uv;
+        }
+        *reinterpret_cast<f32x4 *>(pww + 8 * g) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4 *>(pww + 8 * g + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    };
+
+    // 16 recurrence steps on the block staged at buf_x; y[step][channel] accumulated by the matrix pipe.
+    // Operands of steps 2s+2, 2s+3 are read from LDS while steps 2s, 2s+1 compute; the scheduling barriers keep the
+    // compiler from hoisting all 16 steps' reads to the top (it did: 204 VGPRs, half the occupancy).
+    struct StepOps { float2 dw; f32x4 B, C; };
+    auto recur = [&](const int buf_x) -> f32x4 {
+        const float *xt = reinterpret_cast<const float *>(lds + L::kX + buf_x) + 4 * g;
+        auto slot = [](int sp) { return REV ? TB - 1 - sp : sp; };
+        auto fetch = [&](int sp, StepOps &o) {
+            const int j = slot(sp);
+            o.dw = *reinterpret_cast<const float2 *>(pww + 2 * j);
+            o.B = *reinterpret_cast<const f32x4 *>(xt + j * XS + 16);
+            o.C = *reinterpret_cast<const f32x4 *>(xt + j * XS + 32);
+        };
+        f32x4 yacc = {0.f, 0.f, 0.f, 0.f};
+        auto step = [&](int sp, const StepOps &o) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = cm_exp2(o.dw.x * Ap[i]);
+                h[i] = fmaf(a, h[i], o.dw.y * o.B[i]);
+                part = fmaf(o.C[i], h[i], part);
+            }
+            yacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[slot(sp)], part, yacc, 0, 0, 0);
+        };
+        StepOps q[2][2];
+        fetch(0, q[0][0]);
+        fetch(1, q[0][1]);
+#pragma unroll
+        for (int sg = 0; sg < TB / 2; ++sg) {
+            if (sg + 1 < TB / 2) {
+                fetch(2 * sg + 2, q[(sg + 1) & 1][0]);
+                fetch(2 * sg + 3, q[(sg + 1) & 1][1]);
+            }
+            step(2 * sg, q[sg & 1][0]);
+            step(2 * sg + 1, q[sg & 1][1]);
+            // pin the state here: machine-sink otherwise moves the whole h chain below the last scheduling barrier
+            // (its results are only consumed at the end of the block) and keeps 64 exp results alive instead
+            asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(yacc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return yacc;
+    };
+
+    auto gate = [&](const f32x4 &y) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float ov = fmaf(Dv, uq[i], y[i]);
+            if (has_z) ov *= zq[i] * cm_sigmoid(zq[i]);
+            st_io(orr, o_off, i * o_ts * S, ov, IO{});
+        }
+        o_off += o_step;
+    };
+
+    // tile ring: byte offsets of the (u/z, x_dbl) tiles holding block k, k+1 and the one block k+2 is committed to
+    constexpr int XT = TB * XS * 4;
+    int t_cur = 0, t_nxt = L::kTile, t_fill = 2 * L::kTile;
+    int x_cur = 0, x_nxt = XT, x_fill = 2 * XT;
+    issue();
+    commit(t_cur, x_cur);
+    if (nblk > 1) {
+        issue();
+        commit(t_nxt, x_nxt);
+    }
+    __syncthreads();
+    produce(t_cur, x_cur, tb0);
+    int tb = tb0;
+    for (int k = 0; k < nblk; ++k) {
+        const bool more = k + 2 < nblk;
+        if (more) issue();
+        const f32x4 y = recur(x_cur);
+        gate(y);
+        tb += DIR * TB;
+        if (k + 1 < nblk) produce(t_nxt, x_nxt, tb);
+        if (more) commit(t_fill, x_fill);
+        __syncthreads();
+        const int t_old = t_cur, x_old = x_cur;
+        t_cur = t_nxt; t_nxt = t_fill; t_fill = t_old;
+        x_cur = x_nxt; x_nxt = x_fill; x_fill = x_old;
+    }
+}
+
+template <typename IO>
+__global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_kernel(const cm_scan_cl_args p, const int nx) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[rows_lds<IO>::kBytes];
+    // workgroups of one (batch, direction) share x_dbl rows and neighbouring row segments: keep them on one XCD
+    // (consecutive workgroup ids are dealt round-robin to the 8 XCDs)
+    const int total = gridDim.x;
+    int id = blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int cx = id % nx, b = (id / nx) % p.batch, z = id / (nx * p.batch);
+    const cm_scan_cl_dir &d = p.dir[z];
+    const bool full = p.z != nullptr && p.delta_softplus != 0;
+    if (full) {
+        if (d.reverse_time) scan_rows<IO, true, true>(p, d, lds, cx, b);
+        else scan_rows<IO, false, true>(p, d, lds, cx, b);
+    } else {
+        if (d.reverse_time) scan_rows<IO, true, false>(p, d, lds, cx, b);
+        else scan_rows<IO, false, false>(p, d, lds, cx, b);
+    }
+}
+
+template <typename IO>
+int launch_rows(const cm_scan_cl_args &a) {
+    const int nx = (a.dim + 63) / 64;
+    const long total = (long)nx * a.batch * a.ndir;
+    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO>), dim3((unsigned)total), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a, nx);
+    return cm_launch_status("cm_scan_cl_fwd(rows)");
+}
+
+}  // namespace
+
+// called by cm_scan_cl_fwd (scan_cl_fwd.hip) when every direction carries xdbl
+int cm_scan_rows_fwd(const cm_scan_cl_args &a) {
+    const int vec = a.io_dtype == CM_BF16 ? 8 : 4;
+    CM_REQUIRE(a.io_dtype == CM_BF16 || a.io_dtype == CM_F32, CM_EUNSUPPORTED, "scan_cl_fwd(xdbl): io dtype %d unsupported", a.io_dtype);
+    CM_REQUIRE(a.dim % vec == 0, CM_EUNSUPPORTED, "scan_cl_fwd(xdbl): dim %d must be a multiple of %d", a.dim, vec);
+    CM_REQUIRE(!a.z || (cm_aligned(a.z, 16) && a.z_bs % vec == 0 && a.z_ts % vec == 0), CM_EALIGN,
+               "scan_cl_fwd(xdbl): z must be 16-byte aligned with strides that are multiples of %d", vec);
+    CM_REQUIRE((long)((a.dim + 63) / 64) * a.batch * a.ndir < (1L << 31), CM_EINVAL, "scan_cl_fwd(xdbl): grid too large");
+    for (int i = 0; i < a.ndir; ++i) {
+        const cm_scan_cl_dir &d = a.dir[i];
+        CM_REQUIRE(d.u && d.xdbl && d.A && d.dt_weight && d.out, CM_EINVAL, "scan_cl_fwd(xdbl): dir %d has a NULL tensor", i);
+        CM_REQUIRE(cm_aligned(d.u, 16) && d.u_bs % vec == 0 && d.u_ts % vec == 0 && cm_aligned(d.xdbl, 16) &&
+                       d.xdbl_bs % vec == 0 && d.xdbl_ts % vec == 0 && cm_aligned(d.A, 16) && cm_aligned(d.dt_weight, 16),
+                   CM_EALIGN, "scan_cl_fwd(xdbl): dir %d: u / xdbl / A / dt_weight must be 16-byte aligned, strides multiples of %d", i, vec);
+    }
+    return a.io_dtype == CM_BF16 ? launch_rows<cm_bf16>(a) : launch_rows<float>(a);
+}

@@ -218,6 +218,40 @@ def alloc_bc(nrows: int, batch: int, seqlen: int, device) -> torch.Tensor:
     return flat[:n].view(nrows, batch, seqlen)
 
 
+def pad_dt_weight(dt_weight: torch.Tensor) -> torch.Tensor:
+    """(dim, dt_rank <= 16) -> (dim, 16) fp32, zero padded: the dt_weight layout of cm_scan_cl_fwd's xdbl mode."""
+    d, r = dt_weight.shape
+    if r > 16:
+        raise RuntimeError("the xdbl mode of cm_scan_cl_fwd needs dt_rank <= 16")
+    out = torch.zeros((d, 16), dtype=torch.float32, device=dt_weight.device)
+    out[:, :r] = dt_weight.detach().float()
+    return out
+
+
+def _scan_cl_dir_rows(x, dd, u0, z, keep):
+    """One direction descriptor in xdbl mode: x_dbl rows (batch, seqlen, 48) = [dt16 | B16 | C16] in the I/O dtype."""
+    u, xdbl, dt_w = dd["u"], dd["xdbl"], dd["dt_weight"]
+    _dev_check(u, xdbl, dt_w, dd["A"])
+    _rows_ok(u, "u")
+    _rows_ok(xdbl, "xdbl")
+    b, l, d = u0.shape
+    if u.shape != (b, l, d) or xdbl.shape != (b, l, 48) or u.dtype != u0.dtype or xdbl.dtype != u0.dtype:
+        raise RuntimeError("xdbl mode: u (batch, seqlen, dim) and xdbl (batch, seqlen, 48) must share shape prefix and dtype")
+    if dt_w.shape != (d, 16):
+        raise RuntimeError("xdbl mode: dt_weight must be (dim, 16), zero padded (ops.pad_dt_weight)")
+    A, D, bias, dt_w = _f32c(dd["A"]), _f32c(dd.get("D")), _f32c(dd.get("delta_bias")), _f32c(dt_w)
+    out = dd.get("out")
+    if out is None:
+        out = torch.empty((b, l, d), dtype=u.dtype, device=u.device)
+    _rows_ok(out, "out")
+    keep += [A, D, bias, dt_w]
+    x.u, x.A, x.D, x.delta_bias, x.out, x.dt_weight, x.xdbl = _ptr(u), _ptr(A), _ptr(D), _ptr(bias), _ptr(out), _ptr(dt_w), _ptr(xdbl)
+    x.u_bs, x.u_ts, x.out_bs, x.out_ts = u.stride(0), u.stride(1), out.stride(0), out.stride(1)
+    x.xdbl_bs, x.xdbl_ts, x.dt_rank = xdbl.stride(0), xdbl.stride(1), 16
+    x.reverse_time = int(bool(dd.get("reverse", False)))
+    return out
+
+
 def scan_cl_fwd(directions, z=None, delta_softplus=True):
     """Channels-last selective scan, 1 or 2 directions in one launch (cm_scan_cl_fwd).
 
@@ -239,6 +273,9 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True):
         a.z, a.z_bs, a.z_ts = _ptr(z), z.stride(0), z.stride(1)
     outs = []
     for i, dd in enumerate(directions):
+        if dd.get("xdbl") is not None:
+            outs.append(_scan_cl_dir_rows(a.dir[i], dd, u0, z, keep))
+            continue
         u, delta = dd["u"], dd.get("delta")
         dt_low, dt_w = dd.get("dt_low"), dd.get("dt_weight")
         _dev_check(u, delta, dd["A"], dd["B"], dd["C"], dt_low, dt_w)

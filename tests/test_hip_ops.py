@@ -236,6 +236,57 @@ def test_scan_channels_last_in_kernel_dt_proj(ops, rank):
     close(got, want.transpose(1, 2), 2e-4, 5e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 64), (2, 5, 72), (1, 16, 512), (2, 333, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rank", [9, 16])
+def test_scan_rows_two_directions(ops, shape, dtype, rank):
+    """cm_scan_cl_fwd in xdbl mode (row-group kernel, csrc/scan_rows_fwd.hip): x_proj output rows [dt16 | B | C] read
+    as written, delta formed in-kernel on the matrix pipe, both directions in one launch — against the fp64 oracle on
+    the same (dtype-rounded) inputs.  Ragged sizes: seqlen not a multiple of 16, dim not a multiple of 64."""
+    b, l, e = shape
+    gen = torch.Generator().manual_seed(l * 11 + e + rank)
+    xz = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    z = xz[:, :, e:]
+    dirs, refs = [], []
+    ycat = torch.zeros(b, l, 2 * e, dtype=dtype, device=DEV)
+    xcat = torch.zeros(b, l, 96, dtype=dtype)
+    for i, rev in enumerate((False, True)):
+        u = torch.randn(b, l, e, generator=gen).to(dtype)
+        A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
+        xd = torch.randn(b, l, 48, generator=gen)
+        xd[:, :, rank:16] = 0.0
+        xcat[:, :, 48 * i:48 * (i + 1)] = xd.to(dtype)
+        xd = xcat[:, :, 48 * i:48 * (i + 1)].float()                     # what the kernel sees
+        Wdt = torch.randn(e, rank, generator=gen) * 0.3
+        D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
+        delta = torch.einsum("er,blr->bel", Wdt.double(), xd[:, :, :rank].double())        # (b, e, l), pre-bias
+        Bm, Cm = xd[:, :, 16:32].transpose(1, 2), xd[:, :, 32:48].transpose(1, 2)          # (b, 16, l)
+        f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
+        tr = lambda t: t.float().transpose(1, 2)
+        ref = O.selective_scan(f(tr(u)), f(delta), A, f(Bm), f(Cm), D, f(tr(z)), bias, True, work_dtype=torch.float64)
+        refs.append(f(ref).transpose(1, 2))
+        dirs.append(dict(u=u.to(DEV), A=A.to(DEV), D=D.to(DEV), delta_bias=bias.to(DEV), dt_weight=ops.pad_dt_weight(Wdt.to(DEV)),
+                         out=ycat[:, :, i * e:(i + 1) * e], reverse=rev))
+    gx = xcat.to(DEV)
+    for i in range(2):
+        dirs[i]["xdbl"] = gx[:, :, 48 * i:48 * (i + 1)]
+    ops.scan_cl_fwd(dirs, z=xz.to(DEV)[:, :, e:], delta_softplus=True)
+    tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
+    close(ycat[:, :, :e].float(), refs[0], *tol)
+    close(ycat[:, :, e:].float(), refs[1], *tol)
+    if l > 64:
+        return                      # raw (un-softplused) random time steps grow the state without bound on long inputs
+    # single direction, no z, no D, no bias, no softplus
+    (got,) = ops.scan_cl_fwd([dict(u=dirs[0]["u"], A=dirs[0]["A"], dt_weight=dirs[0]["dt_weight"], xdbl=dirs[0]["xdbl"])],
+                             delta_softplus=False)
+    xd = xcat[:, :, :48].float()
+    Wp = dirs[0]["dt_weight"].cpu()
+    delta = torch.einsum("er,blr->bel", Wp.double(), xd[:, :, :16].double())
+    ref = O.selective_scan(dirs[0]["u"].cpu().float().transpose(1, 2), delta, dirs[0]["A"].cpu(), xd[:, :, 16:32].transpose(1, 2),
+                           xd[:, :, 32:48].transpose(1, 2), None, None, None, False, work_dtype=torch.float64)
+    close(got.float(), ref.transpose(1, 2), *((2e-3, 1e-4) if dtype == torch.float32 else (1.6e-2, 2e-2)))   # growing states: looser rtol
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
