@@ -21,9 +21,12 @@
 // no transposed copy, no fp32 staging buffer.
 #include "cm_common.h"
 
+extern "C" int cm_debug_get();
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TB = 16;        // steps per block (= MFMA M)
 constexpr int NBUF = 3;       // staged input tiles
@@ -34,7 +37,8 @@ template <typename IO> struct rows_lds {
     static constexpr int kTile = TB * 64 * (int)sizeof(IO);
     static constexpr int kU = 0, kZ = NBUF * kTile, kX = 2 * NBUF * kTile;
     static constexpr int kPw = kX + NBUF * TB * XS * 4;
-    static constexpr int kBytes = kPw + 4 * 16 * PWS * 4;
+    static constexpr int kPatch = 4 * 16 * 16 * 4;        // per-wave patch: 4 KB partial-output exchange, overlaid by the
+    static constexpr int kBytes = kPw + 4 * kPatch;       // 2.3 KB (delta', delta'*u) patch while that one is live
 };
 
 template <typename IO> __device__ __forceinline__ float ld_io(const IO *p) { return cm_elem<IO>::load(p); }
@@ -63,7 +67,9 @@ __device__ __forceinline__ void st_io(const __amdgpu_buffer_rsrc_t r, int voff, 
 }
 
 // FULL: z gate and softplus present (the BiMamba layer's call), resolved at compile time
-template <typename IO, bool REV, bool FULL>
+// ABL (timing-only ablations, cm_debug_set): 1 = exp replaced by a multiply-add, 2 = B/C not read from LDS,
+// 3 = no per-(channel,step) owner work (softplus / gate), 4 = plain add instead of the output MFMA, 5 = no staging
+template <typename IO, bool REV, bool FULL, int ABL = 0>
 __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, unsigned char *lds,
                                           const int cx, const int b) {
     using L = rows_lds<IO>;
@@ -125,21 +131,25 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     };
 
     // ---- per-lane constants: 4 states of one channel
-    float Ap[4], Wdt[4], h[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 Ap01, Ap23, h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
+    float Wdt[4];
     {
         const float4 a4 = *reinterpret_cast<const float4 *>(d.A + (int64_t)cc * 16 + 4 * g);
-        Ap[0] = a4.x * CM_LOG2E; Ap[1] = a4.y * CM_LOG2E; Ap[2] = a4.z * CM_LOG2E; Ap[3] = a4.w * CM_LOG2E;
+        Ap01 = f32x2{a4.x * CM_LOG2E, a4.y * CM_LOG2E};
+        Ap23 = f32x2{a4.z * CM_LOG2E, a4.w * CM_LOG2E};
         // B operand of the delta MFMAs: lane (n = channel, k = lane group) holds W_dt[c][4k + q], q = 0..3
         const float4 w4 = *reinterpret_cast<const float4 *>(d.dt_weight + (int64_t)cc * 16 + 4 * g);
         Wdt[0] = w4.x; Wdt[1] = w4.y; Wdt[2] = w4.z; Wdt[3] = w4.w;
     }
     const float bias = d.delta_bias ? d.delta_bias[cc] : 0.f;
     const float Dv = d.D ? d.D[cc] : 0.f;
-    float sel[TB];                                                // A operands of the output MFMAs: one-hot rows
-#pragma unroll
-    for (int j = 0; j < TB; ++j) sel[j] = c16 == j ? 1.f : 0.f;
     float uq[4], zq[4];                                           // (u, z) of the lane's 4 owned steps of the staged block
-    float *pww = reinterpret_cast<float *>(lds + L::kPw) + (w * 16 + c16) * PWS;
+    float *patch = reinterpret_cast<float *>(lds + L::kPw + w * L::kPatch);
+    float *pww = patch + c16 * PWS;
+    // partial-output exchange: [group][channel][16 steps], the 4-step quads of a row XOR-swizzled by channel/4 so that
+    // both the 16-byte writes (lane = channel) and the 16-byte reads are bank-conflict free without padding
+    float *red_w = patch + (g * 16 + c16) * 16;
+    const float *red_r = patch + c16 * 16 + 4 * (g ^ (c16 >> 2));
     int o_off = c_ok ? ((tb0 + 4 * g) * o_ts + c) * S : 0x7fffffff;   // out-of-range offset: stores dropped
     const int o_step = c_ok ? DIR * TB * o_ts * S : 0;
 
@@ -162,7 +172,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float dv = acc[i] + bias;
-            if (softplus) dv = cm_softplus(dv);
+            if (softplus && ABL != 3) dv = cm_softplus(dv);
             if (ragged) dv = tb + 4 * g + i < T ? dv : 0.f;       // padded steps: a = 1, b = 0 (state passes through)
             const float uv = ld_io(ut + i * 64);
             uq[i] = uv;
@@ -184,19 +194,26 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         auto fetch = [&](int sp, StepOps &o) {
             const int j = slot(sp);
             o.dw = *reinterpret_cast<const float2 *>(pww + 2 * j);
-            o.B = *reinterpret_cast<const f32x4 *>(xt + j * XS + 16);
-            o.C = *reinterpret_cast<const f32x4 *>(xt + j * XS + 32);
-        };
-        f32x4 yacc = {0.f, 0.f, 0.f, 0.f};
-        auto step = [&](int sp, const StepOps &o) {
-            float part = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float a = cm_exp2(o.dw.x * Ap[i]);
-                h[i] = fmaf(a, h[i], o.dw.y * o.B[i]);
-                part = fmaf(o.C[i], h[i], part);
+            if constexpr (ABL == 2) { o.B = f32x4{o.dw.x, o.dw.y, o.dw.x, o.dw.y}; o.C = o.B; }
+            else {
+                o.B = *reinterpret_cast<const f32x4 *>(xt + j * XS + 16);
+                o.C = *reinterpret_cast<const f32x4 *>(xt + j * XS + 32);
             }
-            yacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[slot(sp)], part, yacc, 0, 0, 0);
+        };
+        float part[TB];                                           // this lane's 4-state partial outputs, by step
+        // packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 are full rate: two states per instruction)
+        auto step = [&](int sp, const StepOps &o) {
+            const f32x2 d2 = {o.dw.x, o.dw.x}, du2 = {o.dw.y, o.dw.y};
+            const f32x2 x01 = d2 * Ap01, x23 = d2 * Ap23;
+            f32x2 a01, a23;
+            if constexpr (ABL == 1) { a01 = x01 * 0.5f + 1.0f; a23 = x23 * 0.5f + 1.0f; }
+            else { a01 = f32x2{cm_exp2(x01.x), cm_exp2(x01.y)}; a23 = f32x2{cm_exp2(x23.x), cm_exp2(x23.y)}; }
+            const f32x2 b01 = du2 * f32x2{o.B[0], o.B[1]}, b23 = du2 * f32x2{o.B[2], o.B[3]};
+            h01 = __builtin_elementwise_fma(a01, h01, b01);
+            h23 = __builtin_elementwise_fma(a23, h23, b23);
+            f32x2 p2 = f32x2{o.C[0], o.C[1]} * h01;
+            p2 = __builtin_elementwise_fma(f32x2{o.C[2], o.C[3]}, h23, p2);
+            part[slot(sp)] = p2.x + p2.y;
         };
         StepOps q[2][2];
         fetch(0, q[0][0]);
@@ -211,17 +228,28 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             step(2 * sg + 1, q[sg & 1][1]);
             // pin the state here: machine-sink otherwise moves the whole h chain below the last scheduling barrier
             // (its results are only consumed at the end of the block) and keeps 64 exp results alive instead
-            asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(yacc));
+            asm volatile("" : "+v"(h01), "+v"(h23), "+v"(part[slot(2 * sg)]), "+v"(part[slot(2 * sg + 1)]));
             __builtin_amdgcn_sched_barrier(0);
         }
-        return yacc;
+        // sum over the 4 lane groups through the per-wave patch (the (delta', delta'*u) patch is dead by now; LDS
+        // operations of one wave execute in order, so no barrier): afterwards lane (c, g) holds y of steps 4g..4g+3.
+        // (An MFMA with a one-hot A operand per step did this too, but v_mfma_f32_16x16x4_f32 holds the SIMD for 8
+        // passes: 16 of them cost 22 % of the kernel.)
+        if constexpr (ABL == 4) return f32x4{part[0], part[1], part[2], part[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4 *>(red_w + 4 * (q ^ (c16 >> 2))) = f32x4{part[4 * q], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
+        f32x4 y = *reinterpret_cast<const f32x4 *>(red_r);
+#pragma unroll
+        for (int gg = 1; gg < 4; ++gg) y += *reinterpret_cast<const f32x4 *>(red_r + gg * 256);
+        return y;
     };
 
     auto gate = [&](const f32x4 &y) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float ov = fmaf(Dv, uq[i], y[i]);
-            if (has_z) ov *= zq[i] * cm_sigmoid(zq[i]);
+            if (has_z && ABL != 3) ov *= zq[i] * cm_sigmoid(zq[i]);
             st_io(orr, o_off, i * o_ts * S, ov, IO{});
         }
         o_off += o_step;
@@ -241,21 +269,21 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     produce(t_cur, x_cur, tb0);
     int tb = tb0;
     for (int k = 0; k < nblk; ++k) {
-        const bool more = k + 2 < nblk;
+        const bool more = ABL != 5 && k + 2 < nblk;
         if (more) issue();
         const f32x4 y = recur(x_cur);
         gate(y);
         tb += DIR * TB;
         if (k + 1 < nblk) produce(t_nxt, x_nxt, tb);
         if (more) commit(t_fill, x_fill);
-        __syncthreads();
+        if (ABL != 5) __syncthreads();
         const int t_old = t_cur, x_old = x_cur;
         t_cur = t_nxt; t_nxt = t_fill; t_fill = t_old;
         x_cur = x_nxt; x_nxt = x_fill; x_fill = x_old;
     }
 }
 
-template <typename IO>
+template <typename IO, int ABL>
 __global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_kernel(const cm_scan_cl_args p, const int nx) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[rows_lds<IO>::kBytes];
     // workgroups of one (batch, direction) share x_dbl rows and neighbouring row segments: keep them on one XCD
@@ -267,9 +295,9 @@ __global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_ke
     const cm_scan_cl_dir &d = p.dir[z];
     const bool full = p.z != nullptr && p.delta_softplus != 0;
     if (full) {
-        if (d.reverse_time) scan_rows<IO, true, true>(p, d, lds, cx, b);
-        else scan_rows<IO, false, true>(p, d, lds, cx, b);
-    } else {
+        if (d.reverse_time) scan_rows<IO, true, true, ABL>(p, d, lds, cx, b);
+        else scan_rows<IO, false, true, ABL>(p, d, lds, cx, b);
+    } else if constexpr (ABL == 0) {
         if (d.reverse_time) scan_rows<IO, true, false>(p, d, lds, cx, b);
         else scan_rows<IO, false, false>(p, d, lds, cx, b);
     }
@@ -279,7 +307,19 @@ template <typename IO>
 int launch_rows(const cm_scan_cl_args &a) {
     const int nx = (a.dim + 63) / 64;
     const long total = (long)nx * a.batch * a.ndir;
-    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO>), dim3((unsigned)total), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a, nx);
+    const dim3 grid((unsigned)total), block(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    if constexpr (sizeof(IO) == 2) {                    // ablation builds exist for the bf16 kernel only
+        switch (cm_debug_get()) {
+            case 1: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 1>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl1");
+            case 2: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 2>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl2");
+            case 3: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 3>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl3");
+            case 4: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 4>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl4");
+            case 5: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 5>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl5");
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0>), grid, block, 0, st, a, nx);
     return cm_launch_status("cm_scan_cl_fwd(rows)");
 }
 

@@ -46,9 +46,14 @@ def main():
         ref = ycat.clone()
         ops.scan_cl_fwd(new, z=z)
         err = (ycat.float() - ref.float()).abs().max().item()
-        for name, dirs in (("state-split", old), ("row-group", new)):
+        from mamba_asr_amd import _native
+        abls = [int(x) for x in os.environ.get("ABL", "").split(",") if x]
+        cases = [("state-split", old, 0), ("row-group", new, 0)] + [(f"row-group abl{a}", new, a) for a in abls]
+        for name, dirs, abl in cases:
+            _native.lib().cm_debug_set(abl)
             ms = timeit(lambda: ops.scan_cl_fwd(dirs, z=z))
-            print(f"B={b:3d} T={l} {name:12s} {ms * 1e3:8.1f} us  {alg / ms / 1e6:7.1f} GB/s  frac={alg / ms / 1e6 / 8000:.3f}  (max|new-old|={err:.3g})", flush=True)
+            _native.lib().cm_debug_set(0)
+            print(f"B={b:3d} T={l} {name:16s} {ms * 1e3:8.1f} us  {alg / ms / 1e6:7.1f} GB/s  frac={alg / ms / 1e6 / 8000:.3f}  (max|new-old|={err:.3g})", flush=True)
 
 
 if __name__ == "__main__":
