@@ -62,6 +62,20 @@ class _LayerCache:
         xbd[:P, :m.d_inner] = m.x_proj.weight.detach().to(dtype)
         xbd[P:, m.d_inner:] = m.x_proj_b.weight.detach().to(dtype)
         self.x_proj_bd = xbd
+        # row-major variant for cm_scan_cl_fwd's xdbl mode (dt_rank <= 16): output columns per direction are
+        # [dt (zero padded to 16) | B (16) | C (16)], so the scan reads the GEMM's rows as written
+        R, N = self.dt_rank, self.d_state
+        self.rows_mode = R <= 16 and N == 16 and m.d_inner % 8 == 0
+        if self.rows_mode:
+            xr = torch.zeros(96, 2 * m.d_inner, dtype=dtype, device=m.x_proj.weight.device)
+            for i, xp in enumerate((m.x_proj, m.x_proj_b)):
+                wsrc = xp.weight.detach().to(dtype)
+                cols = slice(i * m.d_inner, (i + 1) * m.d_inner)
+                xr[48 * i:48 * i + R, cols] = wsrc[:R]
+                xr[48 * i + 16:48 * i + 48, cols] = wsrc[R:]
+            self.x_proj_rows = xr
+            for d_, dtp in zip(self.dirs, (m.dt_proj, m.dt_proj_b)):
+                d_["dt_w16"] = ops.pad_dt_weight(dtp.weight.detach().to(dtype))      # dtype-rounded like the reference's GEMM operand
         self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
         self.pw_w, self.pw_b = c(cm.bottleneck[0].weight.squeeze(-1)), c(cm.bottleneck[0].bias)
         self.pw_bf, self.lin_bf = f(cm.bottleneck[0].bias), f(cm.after_conv[2].bias)
@@ -108,11 +122,20 @@ def _ffn(x, y_in, p, dtype):
     return torch.addmm(p["b2"], h, p["w2"].t())
 
 
+# cm_scan_cl_fwd's xdbl mode (row-group scan kernel, csrc/scan_rows_fwd.hip); CM_SCAN_ROWS=0 keeps the state-split kernel
+USE_SCAN_ROWS = os.environ.get("CM_SCAN_ROWS", "1") == "1"
+
+
 def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen):
     """x_proj for both directions (one library GEMM, time-contiguous output rows), fp32 feature buffer, and the two
     direction descriptors of cm_scan_cl_fwd."""
     E, R, N = c.d_inner, c.dt_rank, c.d_state
     rows, P = batch * seqlen, c.dt_rank + 2 * c.d_state
+    if c.rows_mode and USE_SCAN_ROWS:
+        xdbl = (ucat.view(rows, 2 * E) @ c.x_proj_rows.t()).view(batch, seqlen, 96)      # one library GEMM, rows as the scan reads them
+        return [dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], D=d["D"], delta_bias=d["dt_bias"], dt_weight=d["dt_w16"],
+                     xdbl=xdbl[:, :, 48 * i:48 * (i + 1)], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
+                for i, d in enumerate(c.dirs)]
     xdblT = c.x_proj_bd @ ucat.view(rows, 2 * E).t()                      # (2P, rows): [dt | B | C] fwd, then bwd
     feat = ops.alloc_bc(2 * P, batch, seqlen, ucat.device)
     feat.view(2 * P, rows).copy_(xdblT)                                   # one bf16 -> fp32 conversion
