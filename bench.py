@@ -34,16 +34,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="conmamba_large_ctc")
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="utterances per GPU (40 s each).  The reference recipe fills 45-80 GB GPUs with 850-1700 s of audio "
-                         "per batch (hparams/CTC/conmamba_large.yaml:108-113); 32 x 40 s = 1280 s on a 288 GB MI355X. "
-                         "SURVEY §8d's 16 x 40 s: --batch 16")
+                         "per batch (hparams/CTC/conmamba_large.yaml:108-113); 64 x 40 s = 2560 s is the same fill of a "
+                         "288 GB MI355X.  SURVEY §8d's 16 x 40 s: --batch 16")
     ap.add_argument("--frames", type=int, default=4000, help="10 ms audio frames per utterance (L)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
-    ap.add_argument("--cpu-batch", type=int, default=32, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -151,7 +151,7 @@ def main():
             # --pmc on tools/pmc_scan.py, profiles/): valid for the configuration it was measured on only
             traffic = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01", "pmc_scan.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r01", "pmc_scan_rows.json")) as f:
                     pmc = json.load(f)
                 w = pmc["workload"]
                 if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (a.batch, a.frames // 4, e_inner, "bf16" if amp is not None else "f32"):
@@ -160,7 +160,7 @@ def main():
                 pass
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "scan_cl_fwd_kernel (cm_scan_cl_fwd: both BiMamba directions per launch)", "avg_launch_us": round(avg_ms * 1e3, 1),
+                    "kernel": "scan_rows_fwd_kernel (cm_scan_cl_fwd, xdbl mode: both BiMamba directions per launch)", "avg_launch_us": round(avg_ms * 1e3, 1),
                     "launches_per_step": len(scans) // 3, "alg_bytes_per_launch": alg_bytes}
 
     base = None

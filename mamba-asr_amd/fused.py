@@ -267,11 +267,12 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
              want_out=next_ln is not None)                                                   # x = norm2(x + 0.5 ffn2)
 
 
-# Utterances are independent through the whole encoder, and its kernels stress different units (the scan is
-# VALU/latency-bound with one workgroup per CU at 16 utterances, the GEMMs are MFMA-bound, the seams HBM-bound): running
-# the batch as three independent parts on three HIP streams lets the hardware overlap them (measured 13.2 -> 12.65 ms per
-# 32-utterance step; 2 parts gave nothing, 4 the same as 3).  CM_STREAMS=1 disables.
-N_STREAMS = int(os.environ.get("CM_STREAMS", "3"))
+# Utterances are independent through the whole encoder, so the batch can run as N independent parts on N HIP streams
+# (captured into the hipGraph): kernels of different parts then overlap each other's launch tails and their
+# load / compute / store phases.  Measured +5 % at 3 streams (64 utterances: 14.56 -> 15.29 M frames/s), but every
+# kernel's own duration then includes the time it shares the chip, which halves the scan's measured roofline fraction;
+# the default is one stream (CM_STREAMS=3 to enable).
+N_STREAMS = int(os.environ.get("CM_STREAMS", "1"))
 _side_streams = {}
 
 
