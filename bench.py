@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=64, help="utterances in the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -153,9 +153,11 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01", "pmc_scan_rows.json")) as f:
                     pmc = json.load(f)
-                w = pmc["workload"]
-                if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (a.batch, a.frames // 4, e_inner, "bf16" if amp is not None else "f32"):
-                    traffic = pmc["traffic_bytes_per_launch"]
+                for run in pmc["runs"]:
+                    w = run["workload"]
+                    if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (units // (2 * (a.frames // 4)), a.frames // 4, e_inner,
+                                                                              "bf16" if amp is not None else "f32"):
+                        traffic = run["traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
