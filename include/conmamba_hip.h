@@ -232,6 +232,27 @@ typedef struct cm_conv_cl_args {
 int cm_conv_cl_fwd(const cm_conv_cl_args *args);
 
 /* ---------------------------------------------------------------------------------------
+ * cm_conv_cl_fwd for both directions fused with both directions' x_proj GEMMs (bf16 only):
+ *   y_fwd, y_bwd as cm_conv_cl_fwd (SiLU applied), and
+ *   xdbl[b,t, 0:48]  = y_fwd[b,t,:] @ Wx_f^T      xdbl[b,t,48:96] = y_bwd[b,t,:] @ Wx_b^T
+ * where Wx_* is the direction's x_proj.weight re-rowed to (48, dim) = [dt rows zero-padded to 16 | B rows | C rows]
+ * (reference selective_scan_interface.py:186 followed by the split of :187-215), bf16, in the fragment-tiled image
+ * cm_ffn_pack_weights produces.  xdbl (batch, seqlen, 96) bf16 is what cm_scan_cl_fwd's xdbl mode reads.
+ * dim: multiple of 32.  Strides in elements, multiples of 4.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_conv_xproj_args {
+    int32_t batch, seqlen, dim, width;
+    const void  *x;
+    const float *weight_f, *bias_f, *weight_b, *bias_b;   /* (dim, 4) / (dim); biases may be NULL */
+    const void  *wx_f, *wx_b;                             /* packed (48, dim) bf16                */
+    void *y_fwd, *y_bwd, *xdbl;
+    int64_t x_bs, x_ts, yf_bs, yf_ts, yb_bs, yb_ts, xdbl_bs, xdbl_ts;
+    void *stream;
+} cm_conv_xproj_args;
+
+int cm_conv_xproj(const cm_conv_xproj_args *args);
+
+/* ---------------------------------------------------------------------------------------
  * Residual add + LayerNorm(s) over the last axis (rows x dim), fused:
  *   r   = x + alpha * y                       (y optional; x fp32 residual stream)
  *   if norm1: r1 = LN(r; g1, b1, eps1) else r1 = r

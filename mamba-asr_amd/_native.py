@@ -82,6 +82,16 @@ class ConvClArgs(C.Structure):
     ]
 
 
+class ConvXprojArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("width", i32),
+        ("x", vp), ("weight_f", fp), ("bias_f", fp), ("weight_b", fp), ("bias_b", fp), ("wx_f", vp), ("wx_b", vp),
+        ("y_fwd", vp), ("y_bwd", vp), ("xdbl", vp),
+        ("x_bs", i64), ("x_ts", i64), ("yf_bs", i64), ("yf_ts", i64), ("yb_bs", i64), ("yb_ts", i64),
+        ("xdbl_bs", i64), ("xdbl_ts", i64), ("stream", vp),
+    ]
+
+
 class AddLnArgs(C.Structure):
     _fields_ = [
         ("rows", i64), ("dim", i32), ("y_dtype", i32), ("out_dtype", i32), ("out_act", i32),
@@ -161,6 +171,7 @@ SYMBOLS = [
     ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
+    ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),

@@ -1,0 +1,164 @@
+// conv_xproj.hip — both BiMamba directions' depthwise conv + SiLU AND their x_proj GEMMs in one pass over x
+// (contract: cm_conv_xproj in include/conmamba_hip.h; reference bimamba.py:223-248 for the two convolutions,
+// selective_scan_interface.py:182-186 for conv -> x_dbl = conv_out @ x_proj.weight^T).
+//
+// Separately this was conv_cl_kernel (read x, write u_fwd | u_bwd) followed by a library GEMM that read the 2E-wide u
+// rows back to produce 96 numbers per row.  Here a workgroup owns 32 steps x all channels of one utterance:
+//   phase 1: every thread convolves 4 channels x 16 steps from a 22-row register window (8-byte loads, 512 B per
+//            wave-instruction), applies SiLU, stores u_fwd / u_bwd to HBM (the scan reads them) and keeps a bf16 copy
+//            in LDS, token-major with a 32-byte row pad (conflict-free 16-byte fragment reads);
+//   phase 2: wave w = (direction, 16-token tile) multiplies its tile by that direction's x_proj weight
+//            (48 x E: [dt rows zero-padded to 16 | B | C]) with v_mfma_f32_16x16x32_bf16, weights as the A operand
+//            straight from their packed image in L2 (cm_ffn_pack_weights layout, 1 KB per fragment), so a lane ends
+//            up with 4 consecutive features of one token = one 8-byte store into the x_dbl row.
+// HBM traffic: x once (+ a 6-row halo per 32), u twice E per step written, 192 B of x_dbl per step.
+#include "cm_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TT = 32;          // steps per workgroup
+constexpr int W = 4;            // conv width
+constexpr int NP = 48;          // x_dbl columns per direction
+constexpr int PF = 4;           // weight-fragment ring depth
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return (uint32_t)cm_elem<cm_bf16>::to_bits(a) | ((uint32_t)cm_elem<cm_bf16>::to_bits(b) << 16);
+}
+__device__ __forceinline__ float silu(float a) { return a * cm_sigmoid(a); }
+
+__global__ __launch_bounds__(256, 2) void conv_xproj_kernel(const cm_conv_xproj_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int E = p.dim, T = p.seqlen;
+    const int XS = E + 16;                                        // LDS row stride in bf16 elements
+    uint16_t *ut[2] = {reinterpret_cast<uint16_t *>(smem), reinterpret_cast<uint16_t *>(smem) + TT * XS};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const uint16_t *xg = reinterpret_cast<const uint16_t *>(p.x) + (int64_t)b * p.x_bs;
+    uint16_t *yf = reinterpret_cast<uint16_t *>(p.y_fwd) + (int64_t)b * p.yf_bs;
+    uint16_t *yb = reinterpret_cast<uint16_t *>(p.y_bwd) + (int64_t)b * p.yb_bs;
+
+    // ---- phase 1: conv + SiLU, both directions.  thread = (4-channel group, half of the 32 steps)
+    const int half = tid >> 7;
+    const int ts = t0 + 16 * half;                                // first step of this thread
+    for (int cg = tid & 127; cg < E / 4; cg += 128) {
+        const int c0 = cg * 4;
+        uint2 raw[16 + 2 * (W - 1)];                              // rows ts-3 .. ts+18, all loads issued first
+#pragma unroll
+        for (int r = 0; r < 16 + 2 * (W - 1); ++r) {
+            const int s = ts - (W - 1) + r;
+            raw[r] = (s >= 0 && s < T) ? *reinterpret_cast<const uint2 *>(xg + (int64_t)s * p.x_ts + c0) : uint2{0u, 0u};
+        }
+        float wf[4][W], wb[4][W], bf[4], bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 f = *reinterpret_cast<const float4 *>(p.weight_f + (c0 + j) * W);
+            const float4 g = *reinterpret_cast<const float4 *>(p.weight_b + (c0 + j) * W);
+            wf[j][0] = f.x; wf[j][1] = f.y; wf[j][2] = f.z; wf[j][3] = f.w;
+            wb[j][0] = g.x; wb[j][1] = g.y; wb[j][2] = g.z; wb[j][3] = g.w;
+            bf[j] = p.bias_f ? p.bias_f[c0 + j] : 0.f;
+            bb[j] = p.bias_b ? p.bias_b[c0 + j] : 0.f;
+        }
+        auto elem = [&](int r, int j) -> float {
+            const uint32_t w2 = j < 2 ? raw[r].x : raw[r].y;
+            return (j & 1) ? cm_bf16_hi(w2) : cm_bf16_lo(w2);
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float of[4], ob[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float af = bf[j], ab = bb[j];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    af = fmaf(wf[j][k], elem(i + k, j), af);                       // x[t-(W-1)+k]
+                    ab = fmaf(wb[j][k], elem(i + 2 * (W - 1) - k, j), ab);         // x[t+(W-1)-k]
+                }
+                of[j] = silu(af);
+                ob[j] = silu(ab);
+            }
+            const uint2 pf = {pack2(of[0], of[1]), pack2(of[2], of[3])};
+            const uint2 pb = {pack2(ob[0], ob[1]), pack2(ob[2], ob[3])};
+            const int tl = 16 * half + i;
+            *reinterpret_cast<uint2 *>(ut[0] + tl * XS + c0) = pf;
+            *reinterpret_cast<uint2 *>(ut[1] + tl * XS + c0) = pb;
+            if (ts + i < T) {
+                *reinterpret_cast<uint2 *>(yf + (int64_t)(ts + i) * p.yf_ts + c0) = pf;
+                *reinterpret_cast<uint2 *>(yb + (int64_t)(ts + i) * p.yb_ts + c0) = pb;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]
+    const int dir = wave >> 1, nt = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nks = E / 32;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(dir ? p.wx_b : p.wx_f), 0, NP * E * 2, 0x00020000);
+    const int vl = lane * 16;
+    bf16x8 wq[PF][3];
+    auto wload = [&](int ks, bf16x8(&dst)[3]) {                   // fragment (band mt, k-tile ks) = 1 KB at (mt*nks + ks)*1024
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+            dst[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, vl, (mt * nks + ks) * 1024, 0));
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) wload(s, wq[s]);                 // past-the-end fragments read as zeros (buffer bounds)
+    f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const uint16_t *frag = ut[dir] + (16 * nt + l15) * XS + lq * 8;
+    for (int ks0 = 0; ks0 < nks; ks0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int ks = ks0 + s;
+            if (ks < nks) {
+                const bf16x8 tok = *reinterpret_cast<const bf16x8 *>(frag + ks * 32);
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][mt], tok, acc[mt], 0, 0, 0);
+                wload(ks + PF, wq[s]);
+            }
+        }
+    }
+    const int t = t0 + 16 * nt + l15;
+    if (t < T) {
+        uint16_t *xo = reinterpret_cast<uint16_t *>(p.xdbl) + (int64_t)b * p.xdbl_bs + (int64_t)t * p.xdbl_ts + dir * NP + lq * 4;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+            *reinterpret_cast<uint2 *>(xo + mt * 16) = uint2{pack2(acc[mt][0], acc[mt][1]), pack2(acc[mt][2], acc[mt][3])};
+    }
+}
+
+}  // namespace
+
+extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "conv_xproj: args is NULL");
+    const cm_conv_xproj_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.seqlen > 0 && a.dim > 0 && a.x && a.weight_f && a.weight_b && a.wx_f && a.wx_b && a.y_fwd &&
+                   a.y_bwd && a.xdbl, CM_EINVAL, "conv_xproj: bad sizes or NULL tensor");
+    CM_REQUIRE(a.width == W, CM_EUNSUPPORTED, "conv_xproj: conv width %d unsupported (4 only)", a.width);
+    CM_REQUIRE(a.dim % 32 == 0 && a.dim <= 2048, CM_EUNSUPPORTED, "conv_xproj: dim %d must be a multiple of 32, at most 2048", a.dim);
+    CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "conv_xproj: batch %d exceeds the grid limit", a.batch);
+    CM_REQUIRE(cm_aligned(a.x, 8) && cm_aligned(a.y_fwd, 8) && cm_aligned(a.y_bwd, 8) && cm_aligned(a.xdbl, 8) &&
+                   cm_aligned(a.weight_f, 16) && cm_aligned(a.weight_b, 16) && cm_aligned(a.wx_f, 16) && cm_aligned(a.wx_b, 16) &&
+                   a.x_bs % 4 == 0 && a.x_ts % 4 == 0 && a.yf_bs % 4 == 0 && a.yf_ts % 4 == 0 && a.yb_bs % 4 == 0 &&
+                   a.yb_ts % 4 == 0 && a.xdbl_bs % 4 == 0 && a.xdbl_ts % 4 == 0,
+               CM_EALIGN, "conv_xproj: tensors must be 8-byte aligned (weights 16) with strides that are multiples of 4 elements");
+    const size_t smem = (size_t)2 * TT * (a.dim + 16) * sizeof(uint16_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_xproj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) {
+            cm_set_error("conv_xproj: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_done = true;
+    }
+    dim3 grid((a.seqlen + TT - 1) / TT, a.batch);
+    hipLaunchKernelGGL(conv_xproj_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_conv_xproj");
+}

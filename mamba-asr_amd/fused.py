@@ -74,6 +74,11 @@ class _LayerCache:
                 xr[48 * i:48 * i + R, cols] = wsrc[:R]
                 xr[48 * i + 16:48 * i + 48, cols] = wsrc[R:]
             self.x_proj_rows = xr
+            # per-direction (48, E) images for cm_conv_xproj (conv + x_proj in one kernel, bf16)
+            self.wx_packed = None
+            if dtype == torch.bfloat16 and m.d_inner % 32 == 0 and xr.is_cuda and m.d_conv == 4:
+                self.wx_packed = [ops.PackedWeight(xr[48 * i:48 * (i + 1), i * m.d_inner:(i + 1) * m.d_inner].contiguous())
+                                  for i in range(2)]
             for d_, dtp in zip(self.dirs, (m.dt_proj, m.dt_proj_b)):
                 d_["dt_w16"] = ops.pad_dt_weight(dtp.weight.detach().to(dtype))      # dtype-rounded like the reference's GEMM operand
         self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
@@ -126,13 +131,18 @@ def _ffn(x, y_in, p, dtype):
 USE_SCAN_ROWS = os.environ.get("CM_SCAN_ROWS", "1") == "1"
 
 
-def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen):
+# cm_conv_xproj: conv (both directions) + x_proj GEMMs in one kernel (bf16); CM_CONV_XPROJ=0 = conv kernel + library GEMM
+USE_CONV_XPROJ = os.environ.get("CM_CONV_XPROJ", "1") == "1"
+
+
+def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen, xdbl=None):
     """x_proj for both directions (one library GEMM, time-contiguous output rows), fp32 feature buffer, and the two
     direction descriptors of cm_scan_cl_fwd."""
     E, R, N = c.d_inner, c.dt_rank, c.d_state
     rows, P = batch * seqlen, c.dt_rank + 2 * c.d_state
     if c.rows_mode and USE_SCAN_ROWS:
-        xdbl = (ucat.view(rows, 2 * E) @ c.x_proj_rows.t()).view(batch, seqlen, 96)      # one library GEMM, rows as the scan reads them
+        if xdbl is None:
+            xdbl = (ucat.view(rows, 2 * E) @ c.x_proj_rows.t()).view(batch, seqlen, 96)  # one library GEMM, rows as the scan reads them
         return [dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], D=d["D"], delta_bias=d["dt_bias"], dt_weight=d["dt_w16"],
                      xdbl=xdbl[:, :, 48 * i:48 * (i + 1)], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
                 for i, d in enumerate(c.dirs)]
@@ -161,10 +171,15 @@ def bimamba_fused(c: _LayerCache, h, batch, seqlen):
         xz = xz + c.in_bias
     xz3 = xz.view(batch, seqlen, 2 * E)
     ucat = torch.empty((batch, seqlen, 2 * E), dtype=xz.dtype, device=xz.device)
-    ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
-                    True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+    xdbl = None
+    if USE_CONV_XPROJ and USE_SCAN_ROWS and c.rows_mode and c.wx_packed is not None and xz.dtype == torch.bfloat16:
+        xdbl = ops.conv_xproj(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                              c.wx_packed[0], c.wx_packed[1], out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+    else:
+        ops.conv_cl_fwd(xz3[:, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                        True, out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
     ycat = torch.empty_like(ucat)
-    dirs = _scan_dirs(c, ucat, ycat, batch, seqlen)
+    dirs = _scan_dirs(c, ucat, ycat, batch, seqlen, xdbl)
     ops.scan_cl_fwd(dirs, z=xz3[:, :, E:], delta_softplus=True)
     y = ycat.view(rows, 2 * E) @ c.out_cat.t()                           # 0.5*(y_f + y_b) @ W_out^T
     if c.out_bias is not None:

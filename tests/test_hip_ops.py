@@ -287,6 +287,29 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     close(got.float(), ref.transpose(1, 2), *((2e-3, 1e-4) if dtype == torch.float32 else (1.6e-2, 2e-2)))   # growing states: looser rtol
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 512), (2, 5, 96), (1, 33, 1024)])
+def test_conv_xproj(ops, shape):
+    """cm_conv_xproj == cm_conv_cl_fwd (bit-exact u) and x_dbl rows == u @ Wx^T computed in fp32 from the bf16 u and
+    bf16 weights (the products the MFMA forms), within bf16 output rounding; x a column slice of a wider [x | z]."""
+    b, l, e = shape
+    gen = torch.Generator().manual_seed(l + e)
+    xz = torch.randn(b, l, 2 * e, generator=gen).bfloat16().to(DEV)
+    x = xz[:, :, :e]
+    wf, wb = torch.randn(e, 4, generator=gen).to(DEV) * 0.5, torch.randn(e, 4, generator=gen).to(DEV) * 0.5
+    bf, bb = torch.randn(e, generator=gen).to(DEV) * 0.1, torch.randn(e, generator=gen).to(DEV) * 0.1
+    wx = [(torch.randn(48, e, generator=gen) * 0.1).bfloat16().to(DEV) for _ in range(2)]
+    ucat = torch.zeros(b, l, 2 * e, dtype=torch.bfloat16, device=DEV)
+    xdbl = ops.conv_xproj(x, wf, bf, wb, bb, ops.PackedWeight(wx[0]), ops.PackedWeight(wx[1]), out_f=ucat[:, :, :e], out_b=ucat[:, :, e:])
+    rf, rb = ops.conv_cl_fwd(x, wf, bf, wb, bb, True)
+    assert torch.equal(ucat[:, :, :e], rf) and torch.equal(ucat[:, :, e:], rb)
+    # independent check of the conv itself against the oracle (time-contiguous layout)
+    ref = O.causal_conv1d(x.float().cpu().transpose(1, 2), wf.cpu(), bf.cpu(), True, work_dtype=torch.float64).transpose(1, 2)
+    close(rf.float(), ref, 1.6e-2, 1e-2)
+    for i, u in enumerate((rf, rb)):
+        want = u.float() @ wx[i].float().t()
+        close(xdbl[:, :, 48 * i:48 * (i + 1)].float(), want, 1.6e-2, 2e-2)
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
