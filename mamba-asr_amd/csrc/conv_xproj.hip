@@ -3,15 +3,15 @@
 // selective_scan_interface.py:182-186 for conv -> x_dbl = conv_out @ x_proj.weight^T).
 //
 // Separately this was conv_cl_kernel (read x, write u_fwd | u_bwd) followed by a library GEMM that read the 2E-wide u
-// rows back to produce 96 numbers per row.  Here a workgroup owns 32 steps x all channels of one utterance:
-//   phase 1: every thread convolves 4 channels x 16 steps from a 22-row register window (8-byte loads, 512 B per
+// rows back to produce 96 numbers per row.  Here a workgroup owns 16 steps x all channels of one utterance:
+//   phase 1: every thread convolves 4 channels x 8 steps from a 14-row register window (8-byte loads, 512 B per
 //            wave-instruction), applies SiLU, stores u_fwd / u_bwd to HBM (the scan reads them) and keeps a bf16 copy
 //            in LDS, token-major with a 32-byte row pad (conflict-free 16-byte fragment reads);
-//   phase 2: wave w = (direction, 16-token tile) multiplies its tile by that direction's x_proj weight
+//   phase 2: wave w < 2 = direction multiplies the 16-token tile by that direction's x_proj weight
 //            (48 x E: [dt rows zero-padded to 16 | B | C]) with v_mfma_f32_16x16x32_bf16, weights as the A operand
 //            straight from their packed image in L2 (cm_ffn_pack_weights layout, 1 KB per fragment), so a lane ends
 //            up with 4 consecutive features of one token = one 8-byte store into the x_dbl row.
-// HBM traffic: x once (+ a 6-row halo per 32), u twice E per step written, 192 B of x_dbl per step.
+// HBM traffic: x once (+ a 6-row halo per 16, served by the XCD's L2), u twice E per step written, 192 B of x_dbl per step.
 #include "cm_common.h"
 
 namespace {
@@ -19,39 +19,53 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int TT = 32;          // steps per workgroup
+constexpr int TT = 16;          // steps per workgroup
+constexpr int TH = TT / 2;      // steps per thread
 constexpr int W = 4;            // conv width
 constexpr int NP = 48;          // x_dbl columns per direction
-constexpr int PF = 4;           // weight-fragment ring depth
+constexpr int PF = 8;           // weight-fragment ring depth
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    return (uint32_t)cm_elem<cm_bf16>::to_bits(a) | ((uint32_t)cm_elem<cm_bf16>::to_bits(b) << 16);
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 __device__ __forceinline__ float silu(float a) { return a * cm_sigmoid(a); }
 
-__global__ __launch_bounds__(256, 2) void conv_xproj_kernel(const cm_conv_xproj_args p) {
+__global__ __launch_bounds__(256, 4) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int E = p.dim, T = p.seqlen;
     const int XS = E + 16;                                        // LDS row stride in bf16 elements
     uint16_t *ut[2] = {reinterpret_cast<uint16_t *>(smem), reinterpret_cast<uint16_t *>(smem) + TT * XS};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, t0 = blockIdx.x * TT;
-    const uint16_t *xg = reinterpret_cast<const uint16_t *>(p.x) + (int64_t)b * p.x_bs;
-    uint16_t *yf = reinterpret_cast<uint16_t *>(p.y_fwd) + (int64_t)b * p.yf_bs;
-    uint16_t *yb = reinterpret_cast<uint16_t *>(p.y_bwd) + (int64_t)b * p.yb_bs;
+    // consecutive step tiles of an utterance share halo rows: keep them on one XCD (workgroup ids are dealt round-robin
+    // to the 8 XCDs)
+    const int total = gridDim.x;
+    int id = blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int b = id / ntile, t0 = (id % ntile) * TT;
+    // buffer descriptors over this utterance's slices: rows outside [0, T) fall outside the buffer (reads return 0 = the
+    // conv's zero padding, stores are dropped) and per-row addresses are an SGPR offset, so no per-access address math
+    const int x_ts = (int)p.x_ts * 2, yf_ts = (int)p.yf_ts * 2, yb_ts = (int)p.yb_ts * 2;      // row strides in bytes
+    auto rsrc = [&](const void *base, int64_t bs, int row_bytes) {
+        const int64_t bytes = (int64_t)(T - 1) * row_bytes + (int64_t)E * 2;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(reinterpret_cast<const uint16_t *>(base) + (int64_t)b * bs), 0,
+                                                 bytes > 0x7fffffff ? 0x7fffffff : (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bs, x_ts), fr = rsrc(p.y_fwd, p.yf_bs, yf_ts), br = rsrc(p.y_bwd, p.yb_bs, yb_ts);
 
-    // ---- phase 1: conv + SiLU, both directions.  thread = (4-channel group, half of the 32 steps)
-    const int half = tid >> 7;
-    const int ts = t0 + 16 * half;                                // first step of this thread
+    // ---- phase 1: conv + SiLU, both directions.  thread = (4-channel group, half of the tile's steps)
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ts = t0 + TH * half;                                // first step of this thread (wave-uniform)
     for (int cg = tid & 127; cg < E / 4; cg += 128) {
         const int c0 = cg * 4;
-        uint2 raw[16 + 2 * (W - 1)];                              // rows ts-3 .. ts+18, all loads issued first
+        u32x2 raw[TH + 2 * (W - 1)];                              // rows ts-3 .. ts+TH+2, all loads issued first
 #pragma unroll
-        for (int r = 0; r < 16 + 2 * (W - 1); ++r) {
-            const int s = ts - (W - 1) + r;
-            raw[r] = (s >= 0 && s < T) ? *reinterpret_cast<const uint2 *>(xg + (int64_t)s * p.x_ts + c0) : uint2{0u, 0u};
-        }
+        for (int r = 0; r < TH + 2 * (W - 1); ++r)
+            raw[r] = __builtin_amdgcn_raw_buffer_load_b64(xr, c0 * 2, (ts - (W - 1) + r) * x_ts, 0);
         float wf[4][W], wb[4][W], bf[4], bb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -63,11 +77,11 @@ __global__ __launch_bounds__(256, 2) void conv_xproj_kernel(const cm_conv_xproj_
             bb[j] = p.bias_b ? p.bias_b[c0 + j] : 0.f;
         }
         auto elem = [&](int r, int j) -> float {
-            const uint32_t w2 = j < 2 ? raw[r].x : raw[r].y;
+            const uint32_t w2 = j < 2 ? raw[r][0] : raw[r][1];
             return (j & 1) ? cm_bf16_hi(w2) : cm_bf16_lo(w2);
         };
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < TH; ++i) {
             float of[4], ob[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -80,21 +94,20 @@ __global__ __launch_bounds__(256, 2) void conv_xproj_kernel(const cm_conv_xproj_
                 of[j] = silu(af);
                 ob[j] = silu(ab);
             }
-            const uint2 pf = {pack2(of[0], of[1]), pack2(of[2], of[3])};
-            const uint2 pb = {pack2(ob[0], ob[1]), pack2(ob[2], ob[3])};
-            const int tl = 16 * half + i;
-            *reinterpret_cast<uint2 *>(ut[0] + tl * XS + c0) = pf;
-            *reinterpret_cast<uint2 *>(ut[1] + tl * XS + c0) = pb;
-            if (ts + i < T) {
-                *reinterpret_cast<uint2 *>(yf + (int64_t)(ts + i) * p.yf_ts + c0) = pf;
-                *reinterpret_cast<uint2 *>(yb + (int64_t)(ts + i) * p.yb_ts + c0) = pb;
-            }
+            const u32x2 pf = {pack2(of[0], of[1]), pack2(of[2], of[3])};
+            const u32x2 pb = {pack2(ob[0], ob[1]), pack2(ob[2], ob[3])};
+            const int tl = TH * half + i;
+            *reinterpret_cast<u32x2 *>(ut[0] + tl * XS + c0) = pf;
+            *reinterpret_cast<u32x2 *>(ut[1] + tl * XS + c0) = pb;
+            __builtin_amdgcn_raw_buffer_store_b64(pf, fr, c0 * 2, (ts + i) * yf_ts, 0);     // steps >= T: out of range, dropped
+            __builtin_amdgcn_raw_buffer_store_b64(pb, br, c0 * 2, (ts + i) * yb_ts, 0);
         }
     }
     __syncthreads();
 
-    // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]
-    const int dir = wave >> 1, nt = wave & 1;
+    // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]; one wave per direction (48 MFMAs)
+    if (wave >= 2) return;
+    const int dir = wave, nt = 0;
     const int l15 = lane & 15, lq = lane >> 4;
     const int nks = E / 32;
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -141,7 +154,6 @@ extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
                    a.y_bwd && a.xdbl, CM_EINVAL, "conv_xproj: bad sizes or NULL tensor");
     CM_REQUIRE(a.width == W, CM_EUNSUPPORTED, "conv_xproj: conv width %d unsupported (4 only)", a.width);
     CM_REQUIRE(a.dim % 32 == 0 && a.dim <= 2048, CM_EUNSUPPORTED, "conv_xproj: dim %d must be a multiple of 32, at most 2048", a.dim);
-    CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "conv_xproj: batch %d exceeds the grid limit", a.batch);
     CM_REQUIRE(cm_aligned(a.x, 8) && cm_aligned(a.y_fwd, 8) && cm_aligned(a.y_bwd, 8) && cm_aligned(a.xdbl, 8) &&
                    cm_aligned(a.weight_f, 16) && cm_aligned(a.weight_b, 16) && cm_aligned(a.wx_f, 16) && cm_aligned(a.wx_b, 16) &&
                    a.x_bs % 4 == 0 && a.x_ts % 4 == 0 && a.yf_bs % 4 == 0 && a.yf_ts % 4 == 0 && a.yb_bs % 4 == 0 &&
@@ -158,7 +170,8 @@ extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
         }
         attr_done = true;
     }
-    dim3 grid((a.seqlen + TT - 1) / TT, a.batch);
-    hipLaunchKernelGGL(conv_xproj_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    const int ntile = (a.seqlen + TT - 1) / TT;
+    CM_REQUIRE((long)ntile * a.batch < (1L << 31), CM_EINVAL, "conv_xproj: grid too large");
+    hipLaunchKernelGGL(conv_xproj_kernel, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile);
     return cm_launch_status("cm_conv_xproj");
 }
