@@ -93,6 +93,18 @@ __device__ __forceinline__ float cm_gelu(float x) {
     return 0.5f * x * (x >= 0.f ? 2.0f - e : e);
 }
 
+// GELU for results that are rounded to bf16 right away (the FFN's hidden activations): x * sigmoid(x * P(x^2)) with
+// P = a + b x^2 + c x^4 fitted (minimax on [-8, 8], scipy Nelder-Mead) to the erf form: max |error| 2.6e-5 absolute,
+// i.e. below half a bf16 ulp wherever |GELU| > 0.013 and far below the error the reference's own bf16 rounding of the
+// pre-activation introduces (4e-3 |x|).  7 plain + 2 transcendental issue slots instead of 16 + 2: in cm_ffn_fused the
+// erf form's VALU work exceeded the MFMA work (profiles/r01: SQ_ACTIVE_INST_VALU 46 % vs MFMA busy 28 %).
+__device__ __forceinline__ float cm_gelu_bf16(float x) {
+    const float x2 = fminf(x * x, 64.0f);                       // beyond |x| = 8 the polynomial would turn over
+    float q = fmaf(x2, 7.03033577e-04f * CM_LOG2E, -7.40112920e-02f * CM_LOG2E);
+    q = fmaf(x2, q, -1.59501577f * CM_LOG2E);                   // -log2(e) * P(x^2)
+    return x * cm_rcp(1.0f + cm_exp2(x * q));
+}
+
 // softplus, beta=1, threshold=20 (torch default; reference selective_scan_interface.py:112).
 // For x < -15, log1p(e^x) == e^x to fp32 precision; using it avoids the 1+tiny cancellation.
 __device__ __forceinline__ float cm_softplus(float x) {

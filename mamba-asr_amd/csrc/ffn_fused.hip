@@ -32,8 +32,10 @@ constexpr int PF = 4;         // weight-fragment ring depth (k-steps in flight)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    return (uint32_t)cm_elem<cm_bf16>::to_bits(a) | ((uint32_t)cm_elem<cm_bf16>::to_bits(b) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
 template <bool ADD>
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 uint2 pk;
-                pk.x = pack2(cm_gelu(acc1[mb][nb][0] + bv.x), cm_gelu(acc1[mb][nb][1] + bv.y));
-                pk.y = pack2(cm_gelu(acc1[mb][nb][2] + bv.z), cm_gelu(acc1[mb][nb][3] + bv.w));
+                pk.x = pack2(cm_gelu_bf16(acc1[mb][nb][0] + bv.x), cm_gelu_bf16(acc1[mb][nb][1] + bv.y));
+                pk.y = pack2(cm_gelu_bf16(acc1[mb][nb][2] + bv.z), cm_gelu_bf16(acc1[mb][nb][3] + bv.w));
                 *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
             }
         }
