@@ -442,10 +442,20 @@ typedef struct cm_fbank_args {
     float *umax_part;            /* optional (batch, ceil(frames / 16)) scratch: cm_fbank_mel_db stores per-tile maxima
                                     there instead of issuing atomics on umax, and cm_fbank_finish reduces them into
                                     umax; pass the same args to both calls */
+    /* cm_fbank_wav only: the STFT is computed in-kernel from the waveform (spec / spec_* are ignored) */
+    const float *wav;            /* (batch, samples) fp32                                                        */
+    const float *window;         /* (n_fft) fp32: the analysis window zero-padded (centred) to n_fft             */
+    const float *twiddle;        /* (n_fft, 2) fp32: exp(-2 pi i k / n_fft), k = 0 .. n_fft - 1                  */
+    int64_t wav_bs;              /* batch stride of wav in elements (even)                                        */
+    int32_t samples, hop, n_fft; /* frames must equal 1 + samples / hop (center=True, zero padding); n_fft 512    */
+    int32_t pad3_;
 } cm_fbank_args;
 
 int cm_fbank_mel_db(const cm_fbank_args *args);
 int cm_fbank_finish(const cm_fbank_args *args);
+/* waveform -> log-mel (before top_db / normalisation: follow with cm_fbank_finish on the same args).  Requires
+ * umax_part and the packed band tables (band_lo, band_hi, band_off, band_w).  In-LDS radix-4 real FFT, n_fft = 512. */
+int cm_fbank_wav(const cm_fbank_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * SpecAugment masking (speechbrain SpectrogramDrop, reference hparams/CTC/conmamba_large.yaml:273-320 and

@@ -149,6 +149,7 @@ class FbankArgs(C.Structure):
         ("spec", fp), ("fbank", fp), ("db", fp), ("umax", fp), ("amin", C.c_float), ("top_db", C.c_float),
         ("mean", fp), ("std", fp), ("band_lo", vp), ("band_hi", vp), ("band_off", vp), ("band_w", fp), ("spec_bs", i64), ("spec_fs", i64), ("spec_ts", i64),
         ("stream", vp), ("umax_part", fp),
+        ("wav", fp), ("window", fp), ("twiddle", fp), ("wav_bs", i64), ("samples", i32), ("hop", i32), ("n_fft", i32), ("pad3_", i32),
     ]
 
 
@@ -181,6 +182,7 @@ SYMBOLS = [
     ("cm_ffn_pack_weights", C.c_int, [vp, i32, i32, vp, vp]),
     ("cm_fbank_mel_db", C.c_int, [C.POINTER(FbankArgs)]),
     ("cm_fbank_finish", C.c_int, [C.POINTER(FbankArgs)]),
+    ("cm_fbank_wav", C.c_int, [C.POINTER(FbankArgs)]),
     ("cm_spec_drop", C.c_int, [C.POINTER(SpecDropArgs)]),
 ]
 

@@ -1,0 +1,183 @@
+// fbank_fft.hip — waveform -> log-mel features in ONE kernel (contract: cm_fbank_wav in include/conmamba_hip.h;
+// speechbrain Fbank semantics as restated in SURVEY Appendix A: STFT(n_fft 512, Hamming window centred in the frame,
+// hop, center=True with zero padding) -> power -> triangular mel -> 10 log10 (floor amin); cm_fbank_finish then
+// applies top_db and the global normalisation).
+//
+// Through the vendor FFT this stage was: pad kernel, frame+window kernel (524 MB written at 64 x 40 s), rocFFT (two
+// kernels + per-chunk copies), then cm_fbank_mel_db reading the 526 MB complex spectrum: ~1.6 ms per 64-utterance step
+// for 6 GFLOP.  Here a wave owns a frame end to end and nothing but the waveform (read ~3.2x through L1/L2: frames
+// overlap) and the 80 log-mel values per frame touch memory:
+//   * real FFT of 512 points = complex FFT of 256 points on z[m] = x[2m] + i x[2m+1] + one split step;
+//   * complex FFT-256 = four radix-4 decimation-in-frequency stages, one butterfly per lane per stage, in place in a
+//     2 KB per-wave LDS buffer (a wave's LDS operations execute in order: no barriers); stage 0 takes its inputs
+//     straight from global memory (8-byte loads, window applied in registers) and the lane's twiddles for the three
+//     twiddled stages stay in registers across frames;
+//   * outputs land in base-4 digit-reversed order, so lane l finds Z[l + 64 i], i = 0..3, in 32 contiguous bytes;
+//   * |X[k]|^2 goes to the [bin][frame] power tile in LDS and the mel / dB stage of cm_fbank_mel_db runs unchanged.
+#include "cm_common.h"
+
+namespace {
+
+constexpr int FT = 16;            // frames per workgroup (4 per wave)
+constexpr int PWS = FT + 1;       // power-tile row stride (odd: conflict-free mel loop)
+constexpr int NF = 512;           // n_fft
+constexpr int NH = NF / 2;        // complex FFT length
+
+struct cf { float re, im; };
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {fmaf(a.re, b.re, -a.im * b.im), fmaf(a.re, b.im, a.im * b.re)}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return {a.im, -a.re}; }      // a * (-i)
+
+// radix-4 DIF butterfly: y_q = sum_r a_r (-i)^{q r}
+__device__ __forceinline__ void bfly4(cf &a0, cf &a1, cf &a2, cf &a3) {
+    const cf b0 = a0 + a2, b1 = a0 - a2, b2 = a1 + a3, b3 = mul_mi(a1 - a3);
+    a0 = b0 + b2; a2 = b0 - b2; a1 = b1 + b3; a3 = b1 - b3;
+}
+
+__device__ __forceinline__ int rev4_8bit(int k) {                     // reverse the four base-4 digits of k < 256
+    return ((k & 3) << 6) | ((k & 12) << 2) | ((k >> 2) & 12) | (k >> 6);
+}
+
+__global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, t0 = blockIdx.x * FT;
+    const int F = NH + 1, T = p.frames, M = p.n_mels;
+    float *pw = sm;                                               // [F][PWS] power tile
+    int *band = reinterpret_cast<int *>(pw + F * PWS);            // [3 M + 1]
+    float *bw = reinterpret_cast<float *>(band + 3 * M + 1);      // [4096] packed band weights
+    cf *zb = reinterpret_cast<cf *>(bw + 4096);                   // [4 waves][NH] FFT work buffers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int m = tid; m < M; m += 256) { band[m] = p.band_lo[m]; band[M + m] = p.band_hi[m]; }
+    for (int m = tid; m <= M; m += 256) band[2 * M + m] = p.band_off[m];
+    {
+        const int total = p.band_off[M];
+        for (int i = tid; i < total; i += 256) bw[i] = p.band_w[i];
+    }
+
+    // ---- per-lane constants
+    const cf *tw = reinterpret_cast<const cf *>(p.twiddle);       // tw[k] = exp(-2 pi i k / 512)
+    cf w0[3], w1[3], w2[3];                                       // twiddles of stages 0..2: W_L^{q j}, q = 1..3
+    {
+        const int j0 = lane, j1 = lane & 15, j2 = lane & 3;
+#pragma unroll
+        for (int q = 1; q <= 3; ++q) {
+            w0[q - 1] = tw[2 * ((q * j0) & 255)];                 // L = 256: W_256^{q j} = tw[2 q j]
+            w1[q - 1] = tw[2 * ((4 * q * j1) & 255)];             // L = 64
+            w2[q - 1] = tw[2 * ((16 * q * j2) & 255)];            // L = 16
+        }
+    }
+    float2 win[4];                                                // window at samples 2m, 2m+1 for m = lane + 64 q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) win[q] = *reinterpret_cast<const float2 *>(p.window + 2 * (lane + 64 * q));
+    // split-step constants for k = lane + 64 i: position of Z[(256 - k) & 255] and exp(-2 pi i k / 512)
+    int ppos[4];
+    cf wk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        ppos[i] = rev4_8bit((NH - k) & (NH - 1));
+        wk[i] = tw[k];
+    }
+    const int r3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);  // Z[lane + 64 i] sits at position 4 r3 + i
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.wav + (int64_t)b * p.wav_bs), 0, p.samples * 4, 0x00020000);
+    cf *z = zb + wave * NH;
+
+    for (int fi = 0; fi < FT / 4; ++fi) {
+        const int j = wave * (FT / 4) + fi, t = t0 + j;           // frame (wave-uniform)
+        if (t < T) {
+            // frame t covers samples t*hop - 256 .. +511 (center=True); outside [0, samples) reads return 0
+            const int s0 = t * p.hop - NH;
+            cf a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = s0 + 2 * (lane + 64 * q);
+                // the 8-byte load may straddle the start (s = -1 cannot happen: s0 and 2m are even) — both samples in or out
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(wr, s * 4, 0, 0);
+                a[q] = cf{__uint_as_float(v[0]) * win[q].x, __uint_as_float(v[1]) * win[q].y};
+            }
+            // stage 0 (L = 256): positions lane + 64 q
+            bfly4(a[0], a[1], a[2], a[3]);
+            z[lane] = a[0];
+            z[lane + 64] = cmul(a[1], w0[0]);
+            z[lane + 128] = cmul(a[2], w0[1]);
+            z[lane + 192] = cmul(a[3], w0[2]);
+            // stage 1 (L = 64): block = lane / 16, j = lane % 16
+            {
+                cf *zz = z + 64 * (lane >> 4) + (lane & 15);
+                a[0] = zz[0]; a[1] = zz[16]; a[2] = zz[32]; a[3] = zz[48];
+                bfly4(a[0], a[1], a[2], a[3]);
+                zz[0] = a[0]; zz[16] = cmul(a[1], w1[0]); zz[32] = cmul(a[2], w1[1]); zz[48] = cmul(a[3], w1[2]);
+            }
+            // stage 2 (L = 16): block = lane / 4, j = lane % 4
+            {
+                cf *zz = z + 16 * (lane >> 2) + (lane & 3);
+                a[0] = zz[0]; a[1] = zz[4]; a[2] = zz[8]; a[3] = zz[12];
+                bfly4(a[0], a[1], a[2], a[3]);
+                zz[0] = a[0]; zz[4] = cmul(a[1], w2[0]); zz[8] = cmul(a[2], w2[1]); zz[12] = cmul(a[3], w2[2]);
+            }
+            // stage 3 (L = 4): positions 4 lane .. 4 lane + 3, no twiddles
+            {
+                cf *zz = z + 4 * lane;
+                a[0] = zz[0]; a[1] = zz[1]; a[2] = zz[2]; a[3] = zz[3];
+                bfly4(a[0], a[1], a[2], a[3]);
+                zz[0] = a[0]; zz[1] = a[1]; zz[2] = a[2]; zz[3] = a[3];
+            }
+            // split step: X[k] = E + (-i) W_512^k O,  E = (Z[k] + conj Z[N-k]) / 2,  O = (Z[k] - conj Z[N-k]) / 2
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const cf A = z[4 * r3 + i], Bc = z[ppos[i]];
+                const cf E = {0.5f * (A.re + Bc.re), 0.5f * (A.im - Bc.im)};
+                const cf O = {0.5f * (A.re - Bc.re), 0.5f * (A.im + Bc.im)};
+                const cf X = E + mul_mi(cmul(O, wk[i]));
+                pw[(lane + 64 * i) * PWS + j] = fmaf(X.re, X.re, X.im * X.im);
+            }
+            if (lane == 0) {                                      // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+                const cf A = z[0];
+                const float x = A.re - A.im;
+                pw[NH * PWS + j] = x * x;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- mel projection + dB (as cm_fbank_mel_db)
+    float local_max = -INFINITY;
+    for (int o = tid; o < FT * M; o += 256) {
+        const int j = o / M, m = o % M;
+        if (t0 + j >= T) continue;
+        float acc = 0.f;
+        const int lo = band[m], hi = band[M + m];
+        const float *wm = bw + band[2 * M + m] - lo;
+        for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], wm[f], acc);
+        const float db = 10.f * log10f(fmaxf(acc, p.amin));
+        p.db[((int64_t)b * T + t0 + j) * M + m] = db;
+        local_max = fmaxf(local_max, db);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off, 64));
+    __syncthreads();
+    if (lane == 0) pw[wave] = local_max;
+    __syncthreads();
+    if (tid == 0) p.umax_part[(int64_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(pw[0], pw[1]), fmaxf(pw[2], pw[3]));
+}
+
+}  // namespace
+
+extern "C" int cm_fbank_wav(const cm_fbank_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "fbank_wav: args is NULL");
+    const cm_fbank_args &a = *args;
+    CM_REQUIRE(a.batch > 0 && a.frames > 0 && a.n_mels > 0 && a.wav && a.window && a.twiddle && a.db && a.umax_part && a.band_lo &&
+                   a.band_hi && a.band_off && a.band_w, CM_EINVAL, "fbank_wav: bad sizes or NULL tensor");
+    CM_REQUIRE(a.n_fft == NF && a.n_freq == NH + 1, CM_EUNSUPPORTED, "fbank_wav: n_fft %d unsupported (512 only)", a.n_fft);
+    CM_REQUIRE(a.hop > 0 && a.hop % 2 == 0 && a.samples > 0 && a.samples < (1 << 29) && a.wav_bs % 2 == 0 && cm_aligned(a.wav, 8) &&
+                   cm_aligned(a.window, 8) && cm_aligned(a.twiddle, 8), CM_EALIGN,
+               "fbank_wav: hop and the batch stride must be even, wav / window / twiddle 8-byte aligned");
+    CM_REQUIRE(a.frames == 1 + a.samples / a.hop, CM_EINVAL, "fbank_wav: frames must be 1 + samples / hop (center=True)");
+    CM_REQUIRE(a.batch <= 65535 && a.n_mels <= 128, CM_EUNSUPPORTED, "fbank_wav: batch / n_mels too large");
+    const size_t smem = (size_t)(NH + 1) * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (size_t)4096 * 4 + (size_t)4 * NH * 8;
+    dim3 grid((a.frames + FT - 1) / FT, a.batch);
+    hipLaunchKernelGGL(fbank_wav_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    return cm_launch_status("cm_fbank_wav");
+}

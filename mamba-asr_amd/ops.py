@@ -620,6 +620,61 @@ def fbank_from_stft(spec, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
     return db
 
 
+_FFT_TABLES = {}
+
+
+def _fft_tables(window: torch.Tensor, n_fft: int):
+    """(window zero-padded and centred to n_fft, twiddles exp(-2 pi i k / n_fft) computed in float64), cached."""
+    key = (window.data_ptr(), window.numel(), n_fft, str(window.device))
+    if key not in _FFT_TABLES:
+        win = torch.zeros(n_fft, dtype=torch.float32, device=window.device)
+        left = (n_fft - window.numel()) // 2
+        win[left:left + window.numel()] = window.float()
+        k = torch.arange(n_fft, dtype=torch.float64)
+        ang = -2.0 * torch.pi * k / n_fft
+        tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).to(torch.float32).to(window.device).contiguous()
+        _FFT_TABLES[key] = (win, tw)
+    return _FFT_TABLES[key]
+
+
+def fbank_wav_supported(n_fft: int, hop: int, n_mels: int) -> bool:
+    return n_fft == 512 and hop % 2 == 0 and n_mels <= 128
+
+
+def fbank_from_wav(wav, window, n_fft, hop, fbank, amin=1e-10, top_db=80.0, mean=None, std=None):
+    """(batch, samples) fp32 waveform -> (batch, 1 + samples // hop, n_mels) fp32 log-mel features, STFT included
+    (cm_fbank_wav + cm_fbank_finish): torch.stft(center=True, pad_mode='constant', window centred in n_fft) semantics."""
+    _dev_check(wav, window, fbank, mean, std)
+    if wav.dtype != torch.float32 or wav.dim() != 2 or wav.stride(1) != 1:
+        wav = wav.float().contiguous()
+    if wav.stride(0) % 2:
+        wav = wav.contiguous() if wav.shape[1] % 2 == 0 else torch.nn.functional.pad(wav, (0, 1))[:, :wav.shape[1]]
+    b, ns = wav.shape
+    fb = _f32c(fbank)
+    nf, m = fb.shape
+    t = 1 + ns // hop
+    win, tw = _fft_tables(window, n_fft)
+    lo, hi, off, packed = _mel_bands(fb)
+    if packed is None:
+        raise RuntimeError("fbank_from_wav: filterbank is not banded (no packed band weights)")
+    db = torch.empty((b, t, m), dtype=torch.float32, device=wav.device)
+    umax = torch.empty((b,), dtype=torch.float32, device=wav.device)
+    part = torch.empty((b, (t + 15) // 16), dtype=torch.float32, device=wav.device)
+    a = N.FbankArgs()
+    a.batch, a.n_freq, a.frames, a.n_mels = b, nf, t, m
+    a.fbank, a.db, a.umax, a.amin, a.top_db = _ptr(fb), _ptr(db), _ptr(umax), float(amin), float(top_db)
+    mean, std = _f32c(mean), _f32c(std)
+    a.mean, a.std = _ptr(mean), _ptr(std)
+    a.band_lo, a.band_hi, a.band_off, a.band_w = _ptr(lo), _ptr(hi), _ptr(off), _ptr(packed)
+    a.umax_part = _ptr(part)
+    a.wav, a.window, a.twiddle, a.wav_bs = _ptr(wav), _ptr(win), _ptr(tw), wav.stride(0)
+    a.samples, a.hop, a.n_fft = ns, hop, n_fft
+    a.stream = _stream()
+    _launch("cm_fbank_wav", N.lib().cm_fbank_wav, a, units=b * t)
+    _launch("cm_fbank_finish", N.lib().cm_fbank_finish, a, units=b * t)
+    return db
+
+
 def spec_drop_(feats, start, length, dim, fill):
     """In-place SpecAugment masking (cm_spec_drop): feats (batch, frames, n_mels) fp32; start/length int32
     (batch, n_masks); dim 1 = time, 2 = frequency; fill = 0-dim device tensor."""

@@ -7,6 +7,7 @@ used instead — nothing below is needed then.  Parity status: "unpinned" (no re
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -87,6 +88,10 @@ class PositionalwiseFeedForward(nn.Module):
 # -------------------------------------------------------------------------------------------
 # frontend: Fbank, InputNormalization, SpectrogramDrop / Augmenter, ConvolutionFrontEnd
 # -------------------------------------------------------------------------------------------
+# cm_fbank_wav (in-LDS FFT, waveform -> log-mel in one kernel) when n_fft == 512; CM_FBANK_WAV=0 = torch.stft + cm_fbank_mel_db
+USE_FBANK_WAV = os.environ.get("CM_FBANK_WAV", "1") == "1"
+
+
 def mel_filterbank(n_mels=80, n_fft=512, sample_rate=16000, f_min=0.0, f_max=None) -> torch.Tensor:
     """Triangular mel filters of speechbrain's Filterbank: (n_fft//2+1, n_mels)."""
     f_max = sample_rate / 2 if f_max is None else f_max
@@ -119,6 +124,11 @@ class Fbank(nn.Module):
     def forward(self, wav, norm=None):
         """``norm`` = (mean, std) folds the global normalisation into the native back end (GPU only)."""
         with torch.autocast(device_type=wav.device.type, enabled=False):          # speechbrain forces fp32 here
+            if wav.is_cuda and USE_FBANK_WAV:
+                from . import ops
+                if ops.fbank_wav_supported(self.n_fft, self.hop, self.n_mels):     # STFT + mel in one native kernel
+                    mean, std = norm if norm is not None else (None, None)
+                    return ops.fbank_from_wav(wav, self.window, self.n_fft, self.hop, self.fbank, self.amin, self.top_db, mean, std)
             spec = torch.stft(wav.float(), self.n_fft, self.hop, self.win, self.window, center=True,
                               pad_mode="constant", normalized=False, onesided=True, return_complex=True)
             if wav.is_cuda:                                                        # native back end (cm_fbank_*)

@@ -70,6 +70,29 @@ def test_native_fbank_backend_matches_torch_restatement():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("samples,win_ms", [(16000, 25), (24317, 25), (4000, 32), (640, 25)])
+def test_fbank_wav_kernel_vs_float64_reference_and_vendor_fft(samples, win_ms, monkeypatch):
+    """cm_fbank_wav (in-LDS radix-4 real FFT + mel + dB) against (a) the independent float64 numpy STFT + mel of
+    _numpy_fbank and (b) the torch.stft (vendor FFT) + cm_fbank_mel_db path it replaces; ragged lengths (samples not a
+    multiple of the hop, fewer frames than a tile), both window lengths the recipes use."""
+    from mamba_asr_amd import sb_compat
+    from mamba_asr_amd.sb_compat import Fbank
+    gen = torch.Generator().manual_seed(samples)
+    wav = (0.1 * torch.randn(3, samples, generator=gen)).clamp(-1, 1)
+    wav[1, samples // 2:] = 0.0                              # a silent tail exercises the amin floor / top_db clamp
+    fb = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=win_ms).to("cuda")
+    got = fb(wav.cuda())
+    assert got.shape == (3, 1 + samples // 160, 80)
+    win = int(round(16 * win_ms))
+    for i in range(3):
+        ref = _numpy_fbank(wav[i].double().numpy(), win=win)
+        np.testing.assert_allclose(got[i].cpu().numpy(), ref, rtol=1e-4, atol=2e-3)
+    monkeypatch.setattr(sb_compat, "USE_FBANK_WAV", False)
+    old = fb(wav.cuda())
+    torch.testing.assert_close(got, old, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim", [1, 2])
 def test_spec_drop_kernel(dim):
     from mamba_asr_amd import ops
