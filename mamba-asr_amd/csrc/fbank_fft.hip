@@ -35,6 +35,10 @@ __device__ __forceinline__ void bfly4(cf &a0, cf &a1, cf &a2, cf &a3) {
     a0 = b0 + b2; a2 = b0 - b2; a1 = b1 + b3; a3 = b1 - b3;
 }
 
+// LDS position of FFT element p: 4 pad elements per 16 spread the strided butterflies of stages 1 and 2 over the banks
+__device__ __forceinline__ int zp(int p) { return p + 4 * (p >> 4); }
+constexpr int ZN = NH + NH / 4;       // padded work-buffer length
+
 __device__ __forceinline__ int rev4_8bit(int k) {                     // reverse the four base-4 digits of k < 256
     return ((k & 3) << 6) | ((k & 12) << 2) | ((k >> 2) & 12) | (k >> 6);
 }
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
     float *pw = sm;                                               // [F][PWS] power tile
     int *band = reinterpret_cast<int *>(pw + F * PWS);            // [3 M + 1]
     float *bw = reinterpret_cast<float *>(band + 3 * M + 1);      // [4096] packed band weights
-    cf *zb = reinterpret_cast<cf *>(bw + 4096);                   // [4 waves][NH] FFT work buffers
+    cf *zb = reinterpret_cast<cf *>(bw + 4096);                   // [4 waves][ZN] FFT work buffers (padded)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int m = tid; m < M; m += 256) { band[m] = p.band_lo[m]; band[M + m] = p.band_hi[m]; }
     for (int m = tid; m <= M; m += 256) band[2 * M + m] = p.band_off[m];
@@ -76,58 +80,63 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
-        ppos[i] = rev4_8bit((NH - k) & (NH - 1));
+        ppos[i] = zp(rev4_8bit((NH - k) & (NH - 1)));
         wk[i] = tw[k];
     }
     const int r3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);  // Z[lane + 64 i] sits at position 4 r3 + i
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.wav + (int64_t)b * p.wav_bs), 0, p.samples * 4, 0x00020000);
-    cf *z = zb + wave * NH;
+    cf *z = zb + wave * ZN;
 
+    // positions (padded) of this lane's butterfly operands in stages 0..3 and of its split-step reads
+    int p0[4], p1[4], p2[4], p3[4], ps[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p0[q] = zp(lane + 64 * q);
+        p1[q] = zp(64 * (lane >> 4) + (lane & 15) + 16 * q);
+        p2[q] = zp(16 * (lane >> 2) + (lane & 3) + 4 * q);
+        p3[q] = zp(4 * lane + q);
+        ps[q] = zp(4 * r3 + q);
+    }
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // frame t covers samples t*hop - 256 .. +255 (center=True); outside [0, samples) the buffer load returns 0.
+    // The 8-byte load never straddles the start: t*hop - 256 and 2m are even.
+    auto fetch = [&](int t, u32x2(&raw)[4]) {
+        const int s0 = t * p.hop - NH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(wr, (s0 + 2 * (lane + 64 * q)) * 4, 0, 0);
+    };
+    u32x2 raw[4], nxt[4];
+    fetch(t0 + wave * (FT / 4), raw);
     for (int fi = 0; fi < FT / 4; ++fi) {
         const int j = wave * (FT / 4) + fi, t = t0 + j;           // frame (wave-uniform)
+        if (fi + 1 < FT / 4) fetch(t + 1, nxt);                   // next frame's samples arrive under this frame's FFT
         if (t < T) {
-            // frame t covers samples t*hop - 256 .. +511 (center=True); outside [0, samples) reads return 0
-            const int s0 = t * p.hop - NH;
             cf a[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s = s0 + 2 * (lane + 64 * q);
-                // the 8-byte load may straddle the start (s = -1 cannot happen: s0 and 2m are even) — both samples in or out
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(wr, s * 4, 0, 0);
-                a[q] = cf{__uint_as_float(v[0]) * win[q].x, __uint_as_float(v[1]) * win[q].y};
-            }
+            for (int q = 0; q < 4; ++q) a[q] = cf{__uint_as_float(raw[q][0]) * win[q].x, __uint_as_float(raw[q][1]) * win[q].y};
             // stage 0 (L = 256): positions lane + 64 q
             bfly4(a[0], a[1], a[2], a[3]);
-            z[lane] = a[0];
-            z[lane + 64] = cmul(a[1], w0[0]);
-            z[lane + 128] = cmul(a[2], w0[1]);
-            z[lane + 192] = cmul(a[3], w0[2]);
+            z[p0[0]] = a[0];
+            z[p0[1]] = cmul(a[1], w0[0]);
+            z[p0[2]] = cmul(a[2], w0[1]);
+            z[p0[3]] = cmul(a[3], w0[2]);
             // stage 1 (L = 64): block = lane / 16, j = lane % 16
-            {
-                cf *zz = z + 64 * (lane >> 4) + (lane & 15);
-                a[0] = zz[0]; a[1] = zz[16]; a[2] = zz[32]; a[3] = zz[48];
-                bfly4(a[0], a[1], a[2], a[3]);
-                zz[0] = a[0]; zz[16] = cmul(a[1], w1[0]); zz[32] = cmul(a[2], w1[1]); zz[48] = cmul(a[3], w1[2]);
-            }
+            a[0] = z[p1[0]]; a[1] = z[p1[1]]; a[2] = z[p1[2]]; a[3] = z[p1[3]];
+            bfly4(a[0], a[1], a[2], a[3]);
+            z[p1[0]] = a[0]; z[p1[1]] = cmul(a[1], w1[0]); z[p1[2]] = cmul(a[2], w1[1]); z[p1[3]] = cmul(a[3], w1[2]);
             // stage 2 (L = 16): block = lane / 4, j = lane % 4
-            {
-                cf *zz = z + 16 * (lane >> 2) + (lane & 3);
-                a[0] = zz[0]; a[1] = zz[4]; a[2] = zz[8]; a[3] = zz[12];
-                bfly4(a[0], a[1], a[2], a[3]);
-                zz[0] = a[0]; zz[4] = cmul(a[1], w2[0]); zz[8] = cmul(a[2], w2[1]); zz[12] = cmul(a[3], w2[2]);
-            }
+            a[0] = z[p2[0]]; a[1] = z[p2[1]]; a[2] = z[p2[2]]; a[3] = z[p2[3]];
+            bfly4(a[0], a[1], a[2], a[3]);
+            z[p2[0]] = a[0]; z[p2[1]] = cmul(a[1], w2[0]); z[p2[2]] = cmul(a[2], w2[1]); z[p2[3]] = cmul(a[3], w2[2]);
             // stage 3 (L = 4): positions 4 lane .. 4 lane + 3, no twiddles
-            {
-                cf *zz = z + 4 * lane;
-                a[0] = zz[0]; a[1] = zz[1]; a[2] = zz[2]; a[3] = zz[3];
-                bfly4(a[0], a[1], a[2], a[3]);
-                zz[0] = a[0]; zz[1] = a[1]; zz[2] = a[2]; zz[3] = a[3];
-            }
+            a[0] = z[p3[0]]; a[1] = z[p3[1]]; a[2] = z[p3[2]]; a[3] = z[p3[3]];
+            bfly4(a[0], a[1], a[2], a[3]);
+            z[p3[0]] = a[0]; z[p3[1]] = a[1]; z[p3[2]] = a[2]; z[p3[3]] = a[3];
             // split step: X[k] = E + (-i) W_512^k O,  E = (Z[k] + conj Z[N-k]) / 2,  O = (Z[k] - conj Z[N-k]) / 2
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const cf A = z[4 * r3 + i], Bc = z[ppos[i]];
+                const cf A = z[ps[i]], Bc = z[ppos[i]];
                 const cf E = {0.5f * (A.re + Bc.re), 0.5f * (A.im - Bc.im)};
                 const cf O = {0.5f * (A.re - Bc.re), 0.5f * (A.im + Bc.im)};
                 const cf X = E + mul_mi(cmul(O, wk[i]));
@@ -139,6 +148,8 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
                 pw[NH * PWS + j] = x * x;
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = nxt[q];
     }
     __syncthreads();
 
@@ -176,7 +187,7 @@ extern "C" int cm_fbank_wav(const cm_fbank_args *args) {
                "fbank_wav: hop and the batch stride must be even, wav / window / twiddle 8-byte aligned");
     CM_REQUIRE(a.frames == 1 + a.samples / a.hop, CM_EINVAL, "fbank_wav: frames must be 1 + samples / hop (center=True)");
     CM_REQUIRE(a.batch <= 65535 && a.n_mels <= 128, CM_EUNSUPPORTED, "fbank_wav: batch / n_mels too large");
-    const size_t smem = (size_t)(NH + 1) * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (size_t)4096 * 4 + (size_t)4 * NH * 8;
+    const size_t smem = (size_t)(NH + 1) * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (size_t)4096 * 4 + (size_t)4 * ZN * 8;
     dim3 grid((a.frames + FT - 1) / FT, a.batch);
     hipLaunchKernelGGL(fbank_wav_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_fbank_wav");
