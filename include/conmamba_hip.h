@@ -349,6 +349,27 @@ typedef struct cm_cnn_block2_args {
 int cm_cnn_block2(const cm_cnn_block2_args *args);
 
 /* ---------------------------------------------------------------------------------------
+ * Both CNN front-end blocks in one kernel: cm_cnn_block1 (pad_out = 1) followed by cm_cnn_block2, without the
+ * (batch, T/2 + 2, F/2 + 2, 64) intermediate ever reaching memory.  F = 80 bins, channels (64, 32).
+ *   feats: (batch, T, 80) fp32      out: (batch, T2, 20 * 32) bf16,  T1 = ceil(T/2),  T2 = (T1 - 1) / 2 + 1
+ *   w1 (64, 1, 3, 3) fp32, b1 (64), ln1_g / ln1_b (40, 64);  w2 (32, 3, 3, 64) bf16 (OHWI), b2 (32) fp32, ln2 (20, 32)
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_cnn_front_args {
+    int32_t batch, T, F, C1, C2;
+    int32_t pad_;
+    const float *feats;
+    const float *w1, *b1, *ln1_g, *ln1_b;
+    const void  *w2;
+    const float *b2, *ln2_g, *ln2_b;
+    float eps1, eps2, slope;
+    int32_t pad2_;
+    void *out;
+    void *stream;
+} cm_cnn_front_args;
+
+int cm_cnn_front(const cm_cnn_front_args *args);
+
+/* ---------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogues for the ConMamba layer's projections:
  *     acc[m, n] = sum_k A[m, k] * W[n, k]            (A: activations, W: nn.Linear weight layout)
  *   epilogue 0:  out = acc + bias                                          -> bf16   (in_proj, pointwise conv)

@@ -92,6 +92,14 @@ class ConvXprojArgs(C.Structure):
     ]
 
 
+class CnnFrontArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("T", i32), ("F", i32), ("C1", i32), ("C2", i32), ("pad_", i32),
+        ("feats", fp), ("w1", fp), ("b1", fp), ("ln1_g", fp), ("ln1_b", fp), ("w2", vp), ("b2", fp), ("ln2_g", fp), ("ln2_b", fp),
+        ("eps1", C.c_float), ("eps2", C.c_float), ("slope", C.c_float), ("pad2_", i32), ("out", vp), ("stream", vp),
+    ]
+
+
 class AddLnArgs(C.Structure):
     _fields_ = [
         ("rows", i64), ("dim", i32), ("y_dtype", i32), ("out_dtype", i32), ("out_act", i32),
@@ -177,6 +185,7 @@ SYMBOLS = [
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
     ("cm_cnn_block2", C.c_int, [C.POINTER(CnnBlock2Args)]),
+    ("cm_cnn_front", C.c_int, [C.POINTER(CnnFrontArgs)]),
     ("cm_gemm_bf16", C.c_int, [C.POINTER(GemmArgs)]),
     ("cm_ffn_fused", C.c_int, [C.POINTER(FfnArgs)]),
     ("cm_ffn_pack_weights", C.c_int, [vp, i32, i32, vp, vp]),

@@ -333,6 +333,10 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None, streams: 
 # ------------------------------------------------------------------------------------------------
 # front end + encoder: the whole path the headline metric times (reference train_CTC.py:285-298)
 # ------------------------------------------------------------------------------------------------
+# cm_cnn_front: both CNN blocks in one kernel; CM_CNN_FRONT=0 = cm_cnn_block1 + cm_cnn_block2
+USE_CNN_FRONT = os.environ.get("CM_CNN_FRONT", "1") == "1"
+
+
 def _frontend_cache(model, dtype):
     c = getattr(model, "_cm_frontend_cache", None)
     ver = sum(p._version for p in model.CNN.parameters()) + sum(p._version for p in model.Transformer.custom_src_module.parameters())
@@ -363,6 +367,14 @@ def asr_encode(model, wavs, wav_lens, dtype: Optional[torch.dtype] = None):
         feats = model.compute_features(wavs, norm=(model.normalize.glob_mean, model.normalize.glob_std))
         c = _frontend_cache(model, dtype)
         b0 = model.CNN.blocks[0]
+        if (USE_CNN_FRONT and dtype == torch.bfloat16 and ops.cnn_front_supported(feats, b0.conv.weight, c["w2_ohwi"])
+                and b0.norm.norm.weight.numel() == 40 * 64):
+            # both CNN blocks in one kernel: the (B, T/2 + 2, 42, 64) intermediate never reaches memory
+            src = ops.cnn_front(feats, b0.conv.weight, b0.conv.bias, b0.norm.norm.weight, b0.norm.norm.bias, b0.norm.norm.eps,
+                                c["w2_ohwi"], c["b2f"], c["ln2"][0], c["ln2"][1], c["ln2"][2], 0.01)
+            batch, t2 = src.shape[0], src.shape[1]
+            x = torch.addmm(c["lin_b"], src.view(batch * t2, -1), c["lin_w"].t())
+            return encoder_forward(model.Transformer.encoder, x.view(batch, t2, -1), dtype)
         y1 = ops.cnn_block1(feats, b0.conv.weight, b0.conv.bias, b0.norm.norm.weight, b0.norm.norm.bias,
                             b0.norm.norm.eps, 0.01, out_dtype=dtype, pad_out=1)     # (B, T1+2, F1+2, 64) NHWC
         if dtype == torch.bfloat16 and tuple(c["w2_ohwi"].shape) == (32, 3, 3, 64):

@@ -444,6 +444,34 @@ def cnn_block1(feats, weight, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01, ou
     return out
 
 
+def cnn_front_supported(feats, w1, w2_ohwi) -> bool:
+    return (feats.shape[-1] == 80 and tuple(w1.shape) == (64, 1, 3, 3) and tuple(w2_ohwi.shape) == (32, 3, 3, 64)
+            and w2_ohwi.dtype == torch.bfloat16 and feats.shape[1] >= 5)
+
+
+def cnn_front(feats, w1, b1, ln1_w, ln1_b, eps1, w2_ohwi, b2, ln2_w, ln2_b, eps2, slope=0.01):
+    """feats (batch, T, 80) fp32 -> (batch, T2, 640) bf16: both ConvolutionFrontEnd blocks in one kernel (cm_cnn_front)."""
+    _dev_check(feats, w1, b1, ln1_w, ln1_b, w2_ohwi, b2, ln2_w, ln2_b)
+    feats = feats.float().contiguous()
+    if not cnn_front_supported(feats, w1, w2_ohwi) or not w2_ohwi.is_contiguous():
+        raise RuntimeError("cnn_front: needs 80 bins, a (64, 1, 3, 3) first conv and a contiguous bf16 (32, 3, 3, 64) second conv")
+    b, t, f = feats.shape
+    t1 = (t + 1) // 2
+    t2 = (t1 - 1) // 2 + 1
+    w1f, b1f, g1, bt1 = _f32c(w1), _f32c(b1), _f32c(ln1_w).reshape(-1), _f32c(ln1_b).reshape(-1)
+    b2f, g2, bt2 = _f32c(b2), _f32c(ln2_w).reshape(-1), _f32c(ln2_b).reshape(-1)
+    if g1.numel() != 40 * 64 or g2.numel() != 20 * 32:
+        raise RuntimeError("cnn_front: LayerNorm parameters must have 40*64 and 20*32 elements")
+    out = torch.empty((b, t2, 640), dtype=torch.bfloat16, device=feats.device)
+    a = N.CnnFrontArgs()
+    a.batch, a.T, a.F, a.C1, a.C2 = b, t, f, 64, 32
+    a.feats, a.w1, a.b1, a.ln1_g, a.ln1_b = _ptr(feats), _ptr(w1f), _ptr(b1f), _ptr(g1), _ptr(bt1)
+    a.w2, a.b2, a.ln2_g, a.ln2_b = _ptr(w2_ohwi), _ptr(b2f), _ptr(g2), _ptr(bt2)
+    a.eps1, a.eps2, a.slope, a.out, a.stream = float(eps1), float(eps2), float(slope), _ptr(out), _stream()
+    _launch("cm_cnn_front", N.lib().cm_cnn_front, a, units=b * t)
+    return out
+
+
 def cnn_block2(y1, weight_ohwi, bias, ln_weight, ln_bias, eps=1e-5, slope=0.01):
     """y1 (batch, T_in, F_in, 64) bf16 channels-last (cnn_block1 output with its reflect border) ->
     (batch, T2, F2*32) bf16: 3x3 stride-2 conv 64 -> 32, LayerNorm over (freq, channel), LeakyReLU (cm_cnn_block2).

@@ -240,6 +240,41 @@ def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt):
         torch.testing.assert_close(h.float().cpu(), want_h, **tol)
 
 
+@pytest.mark.parametrize("batch,frames", [(2, 401), (3, 130), (1, 4001), (2, 37), (70, 64)])
+def test_cnn_front_kernel(batch, frames):
+    """cm_cnn_front (both CNN blocks, intermediate kept in LDS) against (a) a torch fp32 restatement of
+    ConvolutionFrontEnd (reflect 'same' padding, stride 2, LayerNorm over (freq, channel), LeakyReLU) with the block-1
+    output rounded to bf16 where the kernel rounds it, and (b) the two-kernel path cm_cnn_block1 + cm_cnn_block2.
+    Ragged step counts (last tile partial, chunk boundaries), more chunks than workgroups (batch 70)."""
+    from mamba_asr_amd import ops
+    F = torch.nn.functional
+    g = torch.Generator(device="cpu").manual_seed(batch * 1000 + frames)
+    feats = torch.randn(batch, frames, 80, generator=g)
+    w1, b1 = torch.randn(64, 1, 3, 3, generator=g) / 3, torch.randn(64, generator=g) * 0.1
+    g1, be1 = 1.0 + 0.1 * torch.randn(40, 64, generator=g), 0.1 * torch.randn(40, 64, generator=g)
+    w2 = (torch.randn(32, 64, 3, 3, generator=g) * (64 * 9) ** -0.5).bfloat16()
+    b2 = torch.randn(32, generator=g) * 0.1
+    g2, be2 = 1.0 + 0.1 * torch.randn(20, 32, generator=g), 0.1 * torch.randn(20, 32, generator=g)
+    # torch restatement
+    x = F.pad(feats[:, None], (1, 1, 1, 1), mode="reflect")
+    y = F.conv2d(x, w1, b1, stride=2).permute(0, 2, 3, 1)                                   # (B, T1, 40, 64)
+    y = F.leaky_relu(F.layer_norm(y, (40, 64), g1, be1, 1e-5), 0.01).bfloat16().float()
+    y = F.pad(y.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+    z = F.conv2d(y, w2.float(), b2, stride=2).permute(0, 2, 3, 1)                           # (B, T2, 20, 32)
+    t2 = z.shape[1]
+    ref = F.leaky_relu(F.layer_norm(z.reshape(batch, t2, 640), (640,), g2.reshape(-1), be2.reshape(-1), 1e-5), 0.01)
+    d = lambda t: t.to(DEV)
+    w2o = w2.permute(0, 2, 3, 1).contiguous()
+    got = ops.cnn_front(d(feats), d(w1), d(b1), d(g1), d(be1), 1e-5, d(w2o), d(b2), d(g2), d(be2), 1e-5, 0.01)
+    assert got.shape == (batch, t2, 640) and got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1.6e-2, atol=2e-2)
+    assert (got.float().cpu() - ref).abs().mean() < 2e-3
+    y1 = ops.cnn_block1(d(feats), d(w1), d(b1), d(g1), d(be1), 1e-5, 0.01, out_dtype=torch.bfloat16, pad_out=1)
+    two = ops.cnn_block2(y1, d(w2o), d(b2), d(g2), d(be2), 1e-5, 0.01)
+    torch.testing.assert_close(got.float(), two.float(), rtol=1.6e-2, atol=2e-2)
+    assert (got.float() - two.float()).abs().mean() < 1e-3
+
+
 @pytest.mark.parametrize("batch,t_in,f_in", [(2, 42, 42), (3, 37, 42), (1, 9, 22), (2, 11, 9)])
 def test_cnn_block2_kernel(batch, t_in, f_in):
     """cm_cnn_block2 (implicit-GEMM conv 64->32 3x3 s2 + LayerNorm + LeakyReLU) vs torch conv2d/layer_norm in fp32 on the
