@@ -289,7 +289,8 @@ int cm_add_layernorm(const cm_add_ln_args *args);
 typedef struct cm_glu_dwconv_args {
     int32_t batch, seqlen, dim, ksize;
     int32_t io_dtype;
-    int32_t pad_;
+    int32_t glu_done;            /* 0: in is (batch, seqlen, 2*dim) and the GLU is applied here;
+                                    1: in is (batch, seqlen, dim), already gated (cm_ln_pw_glu)      */
     const void  *in;             /* (batch, seqlen, 2*dim), contiguous               */
     const float *weight;         /* (dim, ksize) depthwise taps                       */
     const float *bias;           /* (dim) or NULL                                      */
@@ -302,6 +303,29 @@ typedef struct cm_glu_dwconv_args {
 } cm_glu_dwconv_args;
 
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * Mixer -> convolution-module seam in one kernel (bf16 GEMM operands, d_model 256):
+ *   x_out = x + alpha * y;  h = LayerNorm(x_out; ln_g, ln_b, eps);  pw = h @ W^T + bias  (W: (2*dim, dim));
+ *   out = pw[:, :dim] * sigmoid(pw[:, dim:])                  (reference modules/Conmamba.py:639-640, 441-443)
+ * x (rows, 256) fp32; y (rows, 256) bf16 or NULL; w: the pointwise Conv1d weight (512, 256) bf16 packed with
+ * cm_ffn_pack_weights; bias (512) fp32; x_out (rows, 256) fp32 (may alias x) or NULL; out (rows, 256) bf16, which
+ * cm_glu_dwconv_ln_gelu takes with glu_done = 1.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_ln_pw_glu_args {
+    int32_t rows, dim;
+    const float *x;
+    const void  *y;
+    const float *ln_g, *ln_b;
+    const void  *w;
+    const float *bias;
+    float *x_out;
+    void  *out;
+    float alpha, eps;
+    void *stream;
+} cm_ln_pw_glu_args;
+
+int cm_ln_pw_glu(const cm_ln_pw_glu_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * First block of the CNN front end (speechbrain ConvolutionFrontEnd as configured at reference

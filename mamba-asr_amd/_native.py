@@ -92,6 +92,13 @@ class ConvXprojArgs(C.Structure):
     ]
 
 
+class LnPwGluArgs(C.Structure):
+    _fields_ = [
+        ("rows", i32), ("dim", i32), ("x", fp), ("y", vp), ("ln_g", fp), ("ln_b", fp), ("w", vp), ("bias", fp),
+        ("x_out", fp), ("out", vp), ("alpha", C.c_float), ("eps", C.c_float), ("stream", vp),
+    ]
+
+
 class CnnFrontArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("T", i32), ("F", i32), ("C1", i32), ("C2", i32), ("pad_", i32),
@@ -110,7 +117,7 @@ class AddLnArgs(C.Structure):
 
 class GluDwconvArgs(C.Structure):
     _fields_ = [
-        ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("pad_", i32),
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("glu_done", i32),
         ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
         ("out", vp), ("stream", vp), ("weight_t", fp),
     ]
@@ -183,6 +190,7 @@ SYMBOLS = [
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
+    ("cm_ln_pw_glu", C.c_int, [C.POINTER(LnPwGluArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
     ("cm_cnn_block2", C.c_int, [C.POINTER(CnnBlock2Args)]),
     ("cm_cnn_front", C.c_int, [C.POINTER(CnnFrontArgs)]),

@@ -197,10 +197,20 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
     const int CS = D + 16;                                        // co row stride: rows of one wave land in different banks
     float *co = sm;                                               // [tt][CS] fp32 conv outputs
     IO *g = reinterpret_cast<IO *>(sm + (size_t)tt * CS);         // [nin][D] GLU outputs in the I/O dtype
-    const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * 2 * D;
+    const bool pre = p.glu_done != 0;                              // input already gated: D-wide rows, plain copy
+    const int IW = pre ? D : 2 * D;
+    const IO *in = reinterpret_cast<const IO *>(p.in) + (int64_t)b * T * IW;
     // phase 1: GLU rows -> LDS  (a = in[:, :D], gate = in[:, D:])
     constexpr int NV = cm_elem<IO>::kVec;
-    if (D % NV == 0) {
+    if (pre && D % NV == 0) {
+        for (int idx = threadIdx.x; idx < nin * (D / NV); idx += blockDim.x) {
+            const int r = idx / (D / NV), c = (idx % (D / NV)) * NV;
+            const int t = t0 - K / 2 + r;
+            uint4 v4 = {0u, 0u, 0u, 0u};
+            if (t >= 0 && t < T) v4 = *reinterpret_cast<const uint4 *>(in + (int64_t)t * D + c);
+            *reinterpret_cast<uint4 *>(g + r * D + c) = v4;
+        }
+    } else if (D % NV == 0) {
         for (int idx = threadIdx.x; idx < nin * (D / NV); idx += blockDim.x) {
             const int r = idx / (D / NV), c = (idx % (D / NV)) * NV;
             const int t = t0 - K / 2 + r;
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
             const int t = t0 - K / 2 + r;
             float v0 = 0.f;
             if (t >= 0 && t < T) {
-                const IO *row = in + (int64_t)t * 2 * D;
-                v0 = cm_elem<IO>::load(row + c) * cm_sigmoid(cm_elem<IO>::load(row + D + c));
+                const IO *row = in + (int64_t)t * IW;
+                v0 = pre ? cm_elem<IO>::load(row + c) : cm_elem<IO>::load(row + c) * cm_sigmoid(cm_elem<IO>::load(row + D + c));
             }
             cm_elem<IO>::store(g + r * D + c, v0);
         }
@@ -278,8 +288,10 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
                     const int c = 4 * (l15 + 16 * i);
                     const float4 gm = *reinterpret_cast<const float4 *>(p.ln_g + c);
                     const float4 bt = *reinterpret_cast<const float4 *>(p.ln_b + c);
-                    float o[4] = {gelu_erf(fmaf(v[i].x * rstd, gm.x, bt.x)), gelu_erf(fmaf(v[i].y * rstd, gm.y, bt.y)),
-                                  gelu_erf(fmaf(v[i].z * rstd, gm.z, bt.z)), gelu_erf(fmaf(v[i].w * rstd, gm.w, bt.w))};
+                    // outputs rounded to bf16 take the 7-slot GELU (cm_gelu_bf16: 2.6e-5 from the erf form); fp32 outputs the erf form
+                    auto act = [](float x) { if constexpr (sizeof(IO) == 2) return cm_gelu_bf16(x); else return gelu_erf(x); };
+                    float o[4] = {act(fmaf(v[i].x * rstd, gm.x, bt.x)), act(fmaf(v[i].y * rstd, gm.y, bt.y)),
+                                  act(fmaf(v[i].z * rstd, gm.z, bt.z)), act(fmaf(v[i].w * rstd, gm.w, bt.w))};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cm_elem<IO>::store(out + (int64_t)t * D + c + j, o[j]);
                 }

@@ -84,6 +84,9 @@ class _LayerCache:
         self.cm_ln = (f(cm.layer_norm.weight), f(cm.layer_norm.bias), cm.layer_norm.eps)
         self.pw_w, self.pw_b = c(cm.bottleneck[0].weight.squeeze(-1)), c(cm.bottleneck[0].bias)
         self.pw_bf, self.lin_bf = f(cm.bottleneck[0].bias), f(cm.after_conv[2].bias)
+        self.pw_packed = None                                     # cm_ln_pw_glu's fragment-tiled pointwise-conv weight
+        if dtype == torch.bfloat16 and self.pw_w.is_cuda and tuple(self.pw_w.shape) == (512, 256) and self.pw_bf is not None:
+            self.pw_packed = ops.PackedWeight(self.pw_w)
         self.in_bias_f = None if m.in_proj.bias is None else f(m.in_proj.bias)
         self.out_bias_f = None if m.out_proj.bias is None else f(m.out_proj.bias)
         self.dw_w, self.dw_b = f(cm.conv.weight), f(cm.conv.bias)
@@ -195,15 +198,25 @@ def bimamba_fused(c: _LayerCache, h, batch, seqlen):
 USE_FUSED_FFN = os.environ.get("CM_FUSED_FFN", "1") == "1"
 
 
+# cm_ln_pw_glu: residual add + LayerNorm + pointwise conv + GLU in one kernel; CM_LN_PW_GLU=0 = seam kernel + library GEMM
+USE_LN_PW_GLU = os.environ.get("CM_LN_PW_GLU", "1") == "1"
+
+
 def _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln=None):
     """layer_forward with both feed-forward modules on cm_ffn_fused (bf16, d_model 256)."""
     D = x.shape[-1]
     f1, f2 = c.ffn1, c.ffn2
     _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)   # x += 0.5 ffn1 ; norm1
     y = bimamba_fused(c, h, batch, seqlen)
-    _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)              # x += mamba ; conv-module LN
-    pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)
-    g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
+    if USE_LN_PW_GLU and c.pw_packed is not None and y.dtype == torch.bfloat16 and y.is_contiguous():
+        # x += mamba ; conv-module LN ; pointwise conv ; GLU -- one kernel, the 2D-wide tensor never exists
+        gl = ops.ln_pw_glu(x, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
+        g = ops.glu_dwconv_ln_gelu(gl.view(batch, seqlen, D), c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2],
+                                   weight_t=c.dw_wt, glu_done=True)
+    else:
+        _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)          # x += mamba ; conv-module LN
+        pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)
+        g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
     y = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
     # x = norm2(x + conv + 0.5 ffn2(x + conv)); the encoder's final norm rides along on the last layer
     if final_ln is not None:
@@ -314,7 +327,9 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None, streams: 
         return torch.cat(outs, dim=0)
     batch, seqlen, D = src.shape
     with torch.autocast("cuda", enabled=False):
-        x = src.detach().float().reshape(batch * seqlen, D).contiguous().clone()
+        x = src.detach().float().reshape(batch * seqlen, D).contiguous()
+        if x.data_ptr() == src.data_ptr():
+            x = x.clone()                                     # the residual stream is updated in place
         n = len(encoder.layers)
         fin = (encoder.norm.norm.weight.detach().float(), encoder.norm.norm.bias.detach().float(), encoder.norm.norm.eps)
         caches = [_cache(layer, dtype) for layer in encoder.layers]

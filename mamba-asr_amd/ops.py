@@ -401,7 +401,29 @@ def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_
     return x_out, out
 
 
-def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None):
+def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
+    """Mixer -> convolution-module seam (cm_ln_pw_glu): x_out = x + alpha*y; g = GLU(LayerNorm(x_out) @ W^T + bias).
+    x (rows, 256) fp32 contiguous; y (rows, 256) bf16 or None; norm = (weight, bias, eps); w: PackedWeight of the
+    (512, 256) pointwise-conv weight; bias (512) fp32.  x_out defaults to x (in place).  Returns g (rows, 256) bf16."""
+    _dev_check(x, y, bias)
+    rows, d = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous() or d != 256:
+        raise RuntimeError("ln_pw_glu: x must be a contiguous fp32 (rows, 256) tensor")
+    if y is not None and (y.dtype != torch.bfloat16 or not y.is_contiguous() or y.shape != x.shape):
+        raise RuntimeError("ln_pw_glu: y must be a contiguous bf16 (rows, 256) tensor")
+    if not isinstance(w, PackedWeight) or w.shape != (512, 256):
+        raise RuntimeError("ln_pw_glu: w must be a PackedWeight of shape (512, 256)")
+    g_, b_, bs = _f32c(norm[0]), _f32c(norm[1]), _f32c(bias)
+    xo = x if x_out is None else x_out
+    out = torch.empty((rows, d), dtype=torch.bfloat16, device=x.device)
+    a = N.LnPwGluArgs()
+    a.rows, a.dim, a.x, a.y, a.ln_g, a.ln_b, a.w, a.bias = rows, d, _ptr(x), _ptr(y), _ptr(g_), _ptr(b_), _ptr(w.data), _ptr(bs)
+    a.x_out, a.out, a.alpha, a.eps, a.stream = _ptr(xo), _ptr(out), float(alpha), float(norm[2]), _stream()
+    _launch("cm_ln_pw_glu", N.lib().cm_ln_pw_glu, a, units=rows)
+    return out
+
+
+def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None, glu_done=False):
     """(batch, seqlen, 2*dim) -> (batch, seqlen, dim): GLU, depthwise conv (k=31, same padding), LayerNorm, GELU
     (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k); weight_t: optional precomputed fp32 (k, dim) copy of the
     taps (made here per call otherwise) so that the kernel's per-channel tap reads are coalesced."""
@@ -409,12 +431,12 @@ def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t
     if not inp.is_contiguous():
         inp = inp.contiguous()
     b, l, d2 = inp.shape
-    d = d2 // 2
+    d = d2 if glu_done else d2 // 2                       # glu_done: the input is already gated (cm_ln_pw_glu), dim wide
     w = _f32c(weight).reshape(d, -1)
     bs, g, bt = _f32c(bias), _f32c(ln_weight), _f32c(ln_bias)
     out = torch.empty((b, l, d), dtype=inp.dtype, device=inp.device)
     a = N.GluDwconvArgs()
-    a.batch, a.seqlen, a.dim, a.ksize, a.io_dtype = b, l, d, w.shape[1], _DT[inp.dtype]
+    a.batch, a.seqlen, a.dim, a.ksize, a.io_dtype, a.glu_done = b, l, d, w.shape[1], _DT[inp.dtype], int(bool(glu_done))
     a.in_, a.weight, a.bias, a.ln_g, a.ln_b, a.eps, a.out = _ptr(inp), _ptr(w), _ptr(bs), _ptr(g), _ptr(bt), float(eps), _ptr(out)
     wt = w.t().contiguous() if weight_t is None else weight_t
     if wt.dtype != torch.float32 or wt.shape != (w.shape[1], d) or not wt.is_contiguous():

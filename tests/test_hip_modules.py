@@ -240,6 +240,41 @@ def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt):
         torch.testing.assert_close(h.float().cpu(), want_h, **tol)
 
 
+@pytest.mark.parametrize("batch,seqlen", [(2, 100), (3, 37), (1, 1000)])
+def test_ln_pw_glu_kernel_and_pregated_dwconv(batch, seqlen):
+    """cm_ln_pw_glu (residual add + LayerNorm + pointwise conv + GLU) vs torch fp32 on the same bf16-rounded operands,
+    and cm_glu_dwconv_ln_gelu fed with its D-wide gated output (glu_done) vs the same kernel fed the 2D-wide tensor."""
+    from mamba_asr_amd import ops
+    F = torch.nn.functional
+    g = torch.Generator(device="cpu").manual_seed(seqlen)
+    rows, D = batch * seqlen, 256
+    x = torch.randn(rows, D, generator=g)
+    y = (torch.randn(rows, D, generator=g) * 0.5).bfloat16()
+    ln = (1.0 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g), 1e-5)
+    w = (torch.randn(2 * D, D, generator=g) / 16).bfloat16()
+    bias = torch.randn(2 * D, generator=g) * 0.1
+    r = x + y.float()
+    h = F.layer_norm(r, (D,), ln[0], ln[1], ln[2]).bfloat16().float()
+    pw = h @ w.float().t() + bias
+    want = pw[:, :D] * torch.sigmoid(pw[:, D:])
+    xg = x.to(DEV)
+    got = ops.ln_pw_glu(xg, y.to(DEV), 1.0, (ln[0].to(DEV), ln[1].to(DEV), ln[2]), ops.PackedWeight(w.to(DEV)), bias.to(DEV))
+    torch.testing.assert_close(xg.cpu(), r, rtol=1e-6, atol=1e-6)                  # residual stream updated in place
+    torch.testing.assert_close(got.float().cpu(), want, rtol=1.6e-2, atol=1e-2)
+    assert (got.float().cpu() - want).abs().mean() < 1e-3
+    # depthwise stage: pre-gated input == 2D-wide input whose GLU reproduces it
+    dw_w, dw_b = torch.randn(D, 31, generator=g) / 6, torch.randn(D, generator=g) * 0.1
+    ln2 = (1.0 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g))
+    gl = got.view(batch, seqlen, D)
+    wide = torch.cat([gl.float(), torch.full_like(gl, 40.0, dtype=torch.float32)], dim=-1).bfloat16()       # sigmoid(40) == 1
+    a = ops.glu_dwconv_ln_gelu(gl, dw_w.to(DEV), dw_b.to(DEV), ln2[0].to(DEV), ln2[1].to(DEV), 1e-5, glu_done=True)
+    b_ = ops.glu_dwconv_ln_gelu(wide, dw_w.to(DEV), dw_b.to(DEV), ln2[0].to(DEV), ln2[1].to(DEV), 1e-5)
+    assert torch.equal(a, b_)
+    ref = F.conv1d(gl.float().cpu().transpose(1, 2), dw_w[:, None], dw_b, padding=15, groups=D).transpose(1, 2)
+    ref = F.gelu(F.layer_norm(ref, (D,), ln2[0], ln2[1], 1e-5))
+    torch.testing.assert_close(a.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("batch,frames", [(2, 401), (3, 130), (1, 4001), (2, 37), (70, 64)])
 def test_cnn_front_kernel(batch, frames):
     """cm_cnn_front (both CNN blocks, intermediate kept in LDS) against (a) a torch fp32 restatement of
