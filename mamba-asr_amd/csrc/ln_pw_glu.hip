@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-__global__ __launch_bounds__(256, 2) void ln_pw_glu_kernel(const cm_ln_pw_glu_args p) {
+__global__ __launch_bounds__(256, 3) void ln_pw_glu_kernel(const cm_ln_pw_glu_args p) {
     __shared__ __attribute__((aligned(16))) uint16_t xn[TOK * XS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -37,20 +37,22 @@ __global__ __launch_bounds__(256, 2) void ln_pw_glu_kernel(const cm_ln_pw_glu_ar
     const int t0 = blockIdx.x * TOK, M = p.rows;
     const uint16_t *yv = reinterpret_cast<const uint16_t *>(p.y);
 
-    // weight stream: W (2D, D) packed in 16-row x 32-column fragment images (cm_ffn_pack_weights).  Step s = half * 8 + k-tile:
-    // half 0 = value features wave*64 .. +63, half 1 = their gates (rows D + ...)
+    // weight stream: W (2D, D) packed in 16-row x 32-column fragment images (cm_ffn_pack_weights).  The wave's 64 value
+    // features (and their 64 gates, rows D + ...) are processed in two passes of 32: step s of pass ps = half * 8 + k-tile
+    // (accumulators: 2 halves x 2 bands x 4 token tiles = 64 VGPRs instead of 128 -> 3-4 workgroups per CU, which this
+    // memory-phase-dominated kernel needs more than it needs MFMA density)
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, 2 * D * D * 2, 0x00020000);
     const int vl = lane * 16;
-    auto wload = [&](int s, bf16x8(&dst)[4]) {
+    auto wload = [&](int ps, int s, bf16x8(&dst)[2]) {
         const int half = s >> 3, ks = s & 7;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
             dst[mb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     wr, vl, (((half * D + wave * 64) / 16 + mb) * (D / 32) + ks) * 1024, 0));
+                                                     wr, vl, (((half * D + wave * 64) / 16 + 2 * ps + mb) * (D / 32) + ks) * 1024, 0));
     };
-    bf16x8 wq[PF][4];
+    bf16x8 wq[PF][2];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) wload(s, wq[s]);
+    for (int s = 0; s < PF; ++s) wload(0, s, wq[s]);
 
     // ---- phase 0: x <- x + alpha*y (written back), xn = LayerNorm(x) in bf16.  Wave w owns tokens 16w .. 16w+15, four per
     // round; a row of 16 lanes holds one token (16 floats per lane): statistics = in-lane adds + four DPP steps.
@@ -106,50 +108,52 @@ __global__ __launch_bounds__(256, 2) void ln_pw_glu_kernel(const cm_ln_pw_glu_ar
     }
     lds_barrier();
 
-    // ---- GEMM: (value | gate) features of this wave x 64 tokens, K = 256
-    f32x4 acc[2][4][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[h][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- GEMM + GLU epilogue, two passes of 32 features.  Lane holds token nb*16 + l15, features f0 + mb*16 + j.
     const uint16_t *xfrag = xn + l15 * XS + lq * 8;
     auto read_frags = [&](int ks, bf16x8(&bf)[4]) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const bf16x8 *>(xfrag + nb * 16 * XS + ks * 32);
     };
-    bf16x8 bfa[4], bfb[4];
-    read_frags(0, bfa);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
-        bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
-        if (s + 1 < 16) read_frags((s + 1) & 7, nxt);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                acc[s >> 3][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc[s >> 3][mb][nb], 0, 0, 0);
-        if (s + PF < 16) wload(s + PF, wq[s % PF]);
-        __builtin_amdgcn_sched_barrier(0);                        // keep the refill here (see cm_ffn_fused)
-    }
-
-    // ---- epilogue: bias, GLU, bf16 store.  Lane holds token nb*16 + l15, features wave*64 + mb*16 + lq*4 + j.
-    const int f0 = wave * 64 + lq * 4;
     uint16_t *out = reinterpret_cast<uint16_t *>(p.out);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const float4 ba = *reinterpret_cast<const float4 *>(p.bias + f0 + mb * 16);
-        const float4 bg = *reinterpret_cast<const float4 *>(p.bias + D + f0 + mb * 16);
+    for (int ps = 0; ps < 2; ++ps) {
+        f32x4 acc[2][2][4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int tok = t0 + nb * 16 + l15;
-            const float o0 = (acc[0][mb][nb][0] + ba.x) * cm_sigmoid(acc[1][mb][nb][0] + bg.x);
-            const float o1 = (acc[0][mb][nb][1] + ba.y) * cm_sigmoid(acc[1][mb][nb][1] + bg.y);
-            const float o2 = (acc[0][mb][nb][2] + ba.z) * cm_sigmoid(acc[1][mb][nb][2] + bg.z);
-            const float o3 = (acc[0][mb][nb][3] + ba.w) * cm_sigmoid(acc[1][mb][nb][3] + bg.w);
-            if (tok < M) *reinterpret_cast<uint2 *>(out + (int64_t)tok * D + f0 + mb * 16) = uint2{pack2(o0, o1), pack2(o2, o3)};
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[h][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 bfa[4], bfb[4];
+        read_frags(0, bfa);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+            bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
+            if (s + 1 < 16) read_frags((s + 1) & 7, nxt);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[s >> 3][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc[s >> 3][mb][nb], 0, 0, 0);
+            if (s + PF < 16) wload(ps, s + PF, wq[s % PF]);
+            else if (ps == 0) wload(1, s + PF - 16, wq[s % PF]);  // next pass's first steps
+            __builtin_amdgcn_sched_barrier(0);                    // keep the refill here (see cm_ffn_fused)
+        }
+        const int f0 = wave * 64 + ps * 32 + lq * 4;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float4 ba = *reinterpret_cast<const float4 *>(p.bias + f0 + mb * 16);
+            const float4 bg = *reinterpret_cast<const float4 *>(p.bias + D + f0 + mb * 16);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int tok = t0 + nb * 16 + l15;
+                const float o0 = (acc[0][mb][nb][0] + ba.x) * cm_sigmoid(acc[1][mb][nb][0] + bg.x);
+                const float o1 = (acc[0][mb][nb][1] + ba.y) * cm_sigmoid(acc[1][mb][nb][1] + bg.y);
+                const float o2 = (acc[0][mb][nb][2] + ba.z) * cm_sigmoid(acc[1][mb][nb][2] + bg.z);
+                const float o3 = (acc[0][mb][nb][3] + ba.w) * cm_sigmoid(acc[1][mb][nb][3] + bg.w);
+                if (tok < M) *reinterpret_cast<uint2 *>(out + (int64_t)tok * D + f0 + mb * 16) = uint2{pack2(o0, o1), pack2(o2, o3)};
+            }
         }
     }
 }
