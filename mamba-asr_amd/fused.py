@@ -295,13 +295,94 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
              want_out=next_ln is not None)                                                   # x = norm2(x + 0.5 ffn2)
 
 
-# Utterances are independent through the whole encoder, so the batch can run as N independent parts on N HIP streams
-# (captured into the hipGraph): kernels of different parts then overlap each other's launch tails and their
-# load / compute / store phases.  Measured +5 % at 3 streams (64 utterances: 14.56 -> 15.29 M frames/s), but every
-# kernel's own duration then includes the time it shares the chip, which halves the scan's measured roofline fraction;
-# the default is one stream (CM_STREAMS=3 to enable).
-N_STREAMS = int(os.environ.get("CM_STREAMS", "1"))
+# Utterances are independent through the whole encoder, so the batch can run as N parts on N HIP streams (captured into
+# the hipGraph): kernels of different parts then overlap each other's launch tails and their load / compute / store
+# phases.  Two modes (CM_STREAM_MODE):
+#   "join" (default): every kernel but the selective scan runs per part on its own stream; the scan runs once per layer
+#           on the whole batch between a join and a fork, so the dominant kernel keeps the chip to itself and its launch
+#           duration is its own.  Measured +2.7 % over one stream (64 utterances).
+#   "free": the parts are fully independent.  +7.7-8.6 %, most of it from the VALU-bound scan running beside
+#           memory-bound kernels of the other parts -- but every kernel's duration then includes the time it shares the
+#           chip (the scan's measured roofline fraction halves), so it is not the default.
+# CM_STREAMS=1 disables.
+N_STREAMS = int(os.environ.get("CM_STREAMS", "3"))
+STREAM_MODE = os.environ.get("CM_STREAM_MODE", "join")
 _side_streams = {}
+
+
+def _encoder_forward_joined(encoder, src, dtype, ns):
+    """The fused encoder with the batch as ``ns`` parts on ``ns`` HIP streams for everything EXCEPT the selective scan,
+    which runs once per layer on the whole batch between a join and a fork: the kernels whose load / compute / store
+    phases run in lock step (FFN, seam, conv, GEMMs) overlap across parts, while the dominant kernel keeps the chip to
+    itself (its launch duration is then its own, and its grid is the full batch).  Returns None when a layer is not
+    covered by the all-native bf16 path."""
+    batch, seqlen, D = src.shape
+    if dtype != torch.bfloat16 or not USE_FUSED_FFN or not (USE_CONV_XPROJ and USE_SCAN_ROWS and USE_LN_PW_GLU):
+        return None
+    caches = [_cache(layer, dtype) for layer in encoder.layers]
+    for c in caches:
+        if not (ops.ffn_supported(D, c.ffn1["w1"].shape[0], dtype) and c.ffn2["w1"].shape[0] == c.ffn1["w1"].shape[0] and c.rows_mode
+                and c.wx_packed is not None and c.pw_packed is not None and c.in_bias is None and c.out_bias is None and c.gamma is None):
+            return None
+    dev = src.device
+    cur = torch.cuda.current_stream(dev)
+    pool = _side_streams.setdefault(dev.index, [])
+    while len(pool) < ns - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    streams = [cur] + pool[:ns - 1]
+    edges = [int(round(i * batch / ns)) for i in range(ns + 1)]
+    parts = [(edges[i], edges[i + 1]) for i in range(ns) if edges[i + 1] > edges[i]]
+    E = caches[0].d_inner
+    n = len(encoder.layers)
+    fin = (encoder.norm.norm.weight.detach().float(), encoder.norm.norm.bias.detach().float(), encoder.norm.norm.eps)
+    with torch.autocast("cuda", enabled=False):
+        x = src.detach().float().reshape(batch * seqlen, D).contiguous()
+        if x.data_ptr() == src.data_ptr():
+            x = x.clone()
+        xz = torch.empty((batch, seqlen, 2 * E), dtype=dtype, device=dev)
+        ucat, ycat = torch.empty_like(xz), torch.empty_like(xz)
+        xdbl = torch.empty((batch, seqlen, 96), dtype=dtype, device=dev)
+        outs = [None] * len(parts)
+
+        def fork():
+            for st in streams[1:len(parts)]:
+                st.wait_stream(cur)
+
+        def join():
+            for st in streams[1:len(parts)]:
+                cur.wait_stream(st)
+
+        fork()
+        for li, c in enumerate(caches):
+            f1, f2 = c.ffn1, c.ffn2
+            for pi, (b0, b1) in enumerate(parts):
+                with torch.cuda.stream(streams[pi]):
+                    xp = x[b0 * seqlen:b1 * seqlen]
+                    _, h = ops.ffn_fused(xp, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)
+                    torch.mm(h, c.in_proj.t(), out=xz[b0:b1].view(-1, 2 * E))
+                    ops.conv_xproj(xz[b0:b1, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                                   c.wx_packed[0], c.wx_packed[1], out_f=ucat[b0:b1, :, :E], out_b=ucat[b0:b1, :, E:], xdbl=xdbl[b0:b1])
+            join()
+            ops.scan_cl_fwd(_scan_dirs(c, ucat, ycat, batch, seqlen, xdbl), z=xz[:, :, E:], delta_softplus=True)
+            fork()
+            for pi, (b0, b1) in enumerate(parts):
+                with torch.cuda.stream(streams[pi]):
+                    xp = x[b0 * seqlen:b1 * seqlen]
+                    y = ycat[b0:b1].view(-1, 2 * E) @ c.out_cat.t()
+                    gl = ops.ln_pw_glu(xp, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
+                    g = ops.glu_dwconv_ln_gelu(gl.view(b1 - b0, seqlen, D), c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2],
+                                               weight_t=c.dw_wt, glu_done=True)
+                    yl = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
+                    if li == n - 1:
+                        _, outs[pi] = ops.ffn_fused(xp, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=yl,
+                                                    norm1=c.norm2, norm2=fin, h_dtype=torch.float32)
+                    else:
+                        ops.ffn_fused(xp, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=yl, norm1=c.norm2,
+                                      want_h=False)
+        join()
+        for o in outs[1:]:
+            o.record_stream(cur)
+        return torch.cat(outs, dim=0).view(batch, seqlen, D)
 
 
 @torch.no_grad()
@@ -310,6 +391,10 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None, streams: 
     if dtype is None:
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
     ns = N_STREAMS if streams is None else streams
+    if ns > 1 and src.shape[0] >= 2 * 8 and STREAM_MODE == "join":
+        out = _encoder_forward_joined(encoder, src, dtype, ns)
+        if out is not None:
+            return out
     if ns > 1 and src.shape[0] >= 2 * 8:                       # split only batches large enough to keep each half busy
         dev = src.device
         cur = torch.cuda.current_stream(dev)

@@ -363,6 +363,39 @@ def test_fused_ffn_layer_path_matches_library_path(monkeypatch):
     assert (got - ref32).abs().mean() <= 1.2 * (ref - ref32).abs().mean()
 
 
+@pytest.mark.parametrize("mode", ["join", "free"])
+def test_multi_stream_encoder_matches_single_stream(monkeypatch, mode):
+    """CM_STREAMS=3: the batch as three parts on three HIP streams ('join': scan once per layer on the whole batch
+    between a join and a fork; 'free': independent parts) gives exactly the single-stream result (utterances are
+    independent through the encoder; every kernel is deterministic), eagerly and under hipGraph capture."""
+    from mamba_asr_amd import fused
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    torch.manual_seed(11)
+    enc = ConmambaEncoder(num_layers=3, d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True,
+                          dropout=0.0, causal=False, mamba_config=dict(CFG)).to(DEV).eval()
+    for p in enc.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_normal_(p)
+    x = torch.randn(17, 75, 256, device=DEV)                   # 17 utterances: uneven parts (6, 5, 6)
+    monkeypatch.setattr(fused, "STREAM_MODE", mode)
+    with torch.no_grad():
+        ref = fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=1)
+        got = fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=3)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=3)          # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            out = fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=3)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 def test_native_gemm_layer_path_matches_library_path(monkeypatch):
     """Encoder forward with every projection on cm_gemm_bf16 (fused epilogues) == the library-GEMM fused path."""
     from mamba_asr_amd import fused
