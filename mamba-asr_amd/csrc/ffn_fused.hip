@@ -25,7 +25,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int D = 256;        // d_model
-constexpr int TOK = 64;       // tokens per workgroup
+constexpr int TH = 1;         // token halves per workgroup: waves (th, fq) = (token half, feature quarter); the two waves of
+                              // a feature quarter stream the SAME weight fragments.  TH = 2 (128 tokens, 8 waves) was measured: 109 vs 100 us per
+                              // 64k rows -- the L2 weight stream is not what bounds this kernel
+constexpr int TOK = 64 * TH;  // tokens per workgroup
+constexpr int NT = 256 * TH;  // threads per workgroup
 constexpr int XS = 264;       // LDS row stride in bf16 elements (528 bytes)
 constexpr int CH = 256;       // hidden slab
 constexpr int PF = 4;         // weight-fragment ring depth (k-steps in flight)
@@ -39,7 +43,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 }
 
 template <bool ADD>
-__global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) {
+__global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
     uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab
@@ -47,7 +51,9 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
     float *b1s = red + 4 * TOK;                                   // [hidden] first bias (a global load inside the slab
                                                                   // loop would wait on vmcnt and drain the weight ring)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // uniform: it feeds the buffer loads' scalar offset
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 4*TH-1: owns tokens 16 wv .. +15 in the LayerNorm phases
+    const int wave = wv & 3;                                      // feature quarter (uniform: feeds the buffer loads' scalar offset)
+    const int th = wv >> 2;                                       // token half in the GEMMs / epilogue
     const int l15 = lane & 15, lq = lane >> 4;
     const int t0 = blockIdx.x * TOK, M = p.rows, F = p.hidden;
     const int nch = F / CH;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
 #pragma unroll
     for (int s = 0; s < PF; ++s) wload(0, s, wq[s]);
 
-    for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
+    for (int i = tid; i < p.hidden; i += NT) b1s[i] = p.b1[i];
 
     // ---- phase 0: xin = x (+ add_scale * addend); xn = LayerNorm_pre(xin) in bf16.
     // Wave w owns tokens 16w .. 16w+15, four per round: a row of 16 lanes holds one token (16 floats per lane), so the
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
         float4 v[4][4];
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
-            const int tok = min(t0 + wave * 16 + rd * 4 + lq, M - 1);
+            const int tok = min(t0 + wv * 16 + rd * 4 + lq, M - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[rd][i] = load_x4(tok, (l15 + 16 * i) * 4);
         }
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
                 q = fmaf(v[rd][i].x, v[rd][i].x, fmaf(v[rd][i].y, v[rd][i].y, fmaf(v[rd][i].z, v[rd][i].z, fmaf(v[rd][i].w, v[rd][i].w, q))));
             }
             const float rstd = rsqrtf(cm_group_sum<16>(q) * (1.f / D) + p.pre_eps);
-            uint16_t *dst = xn + (wave * 16 + rd * 4 + lq) * XS;
+            uint16_t *dst = xn + (wv * 16 + rd * 4 + lq) * XS;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = (l15 + 16 * i) * 4;
@@ -142,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint16_t *xfrag = xn + l15 * XS + lq * 8;
-    const uint16_t *hfrag = hc + l15 * XS + lq * 8;
-    uint16_t *hdst = hc + l15 * XS + wave * 64 + lq * 4;
+    const uint16_t *xfrag = xn + (th * 64 + l15) * XS + lq * 8;
+    const uint16_t *hfrag = hc + (th * 64 + l15) * XS + lq * 8;
+    uint16_t *hdst = hc + (th * 64 + l15) * XS + wave * 64 + lq * 4;
 
     auto read_frags = [&](const uint16_t *base, int ks, bf16x8(&bf)[4]) {
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
         if constexpr (LAST) {                                     // residual rows for the epilogue: in flight under GEMM 2
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const int tok = min(t0 + nb * 16 + l15, M - 1);
+                const int tok = min(t0 + th * 64 + nb * 16 + l15, M - 1);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     const float4 xv = load_x4(tok, f0 + mb * 16);
@@ -245,12 +251,12 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
         lds_barrier();                                            // previous use of red is over
         if (lq == 0) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) red[wave * TOK + nb * 16 + l15] = v[nb];
+            for (int nb = 0; nb < 4; ++nb) red[wave * TOK + th * 64 + nb * 16 + l15] = v[nb];
         }
         lds_barrier();
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int t = nb * 16 + l15;
+            const int t = th * 64 + nb * 16 + l15;
             v[nb] = (red[t] + red[TOK + t]) + (red[2 * TOK + t] + red[3 * TOK + t]);
         }
     };
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
     if (p.x_out) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int tok = t0 + nb * 16 + l15;
+            const int tok = t0 + th * 64 + nb * 16 + l15;
             if (tok < M) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const cm_ffn_args p) 
         if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int tok = t0 + nb * 16 + l15;
+            const int tok = t0 + th * 64 + nb * 16 + l15;
             if (tok < M) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
@@ -343,7 +349,7 @@ int launch(const cm_ffn_args &a) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<ADD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
@@ -351,7 +357,7 @@ int launch(const cm_ffn_args &a) {
         attr_done = true;
     }
     dim3 grid((a.rows + TOK - 1) / TOK);
-    hipLaunchKernelGGL((ffn_fused_kernel<ADD>), grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    hipLaunchKernelGGL((ffn_fused_kernel<ADD>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_ffn_fused");
 }
 
