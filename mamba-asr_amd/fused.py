@@ -300,12 +300,13 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
 # phases.  Two modes (CM_STREAM_MODE):
 #   "join" (default): every kernel but the selective scan runs per part on its own stream; the scan runs once per layer
 #           on the whole batch between a join and a fork, so the dominant kernel keeps the chip to itself and its launch
-#           duration is its own.  Measured +2.7 % over one stream (64 utterances).
+#           duration is its own.  Measured over one stream at 64 utterances: 2 parts +2.5 %, 3 parts +3.5 %, 4 parts +6.5 %,
+#           6 parts -4 %.
 #   "free": the parts are fully independent.  +7.7-8.6 %, most of it from the VALU-bound scan running beside
 #           memory-bound kernels of the other parts -- but every kernel's duration then includes the time it shares the
 #           chip (the scan's measured roofline fraction halves), so it is not the default.
 # CM_STREAMS=1 disables.
-N_STREAMS = int(os.environ.get("CM_STREAMS", "3"))
+N_STREAMS = int(os.environ.get("CM_STREAMS", "4"))
 STREAM_MODE = os.environ.get("CM_STREAM_MODE", "join")
 _side_streams = {}
 
