@@ -114,6 +114,10 @@ __device__ __forceinline__ float cm_softplus(float x) {
     return x > 20.0f ? x : sp;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it makes every wave wait for its
+// outstanding global STORES (and prefetch loads) at each barrier; kernels that barrier inside a streaming loop use this.
+__device__ __forceinline__ void cm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // DPP helpers (full-rate cross-lane moves inside a row of 16 lanes)
 template <int CTRL> __device__ __forceinline__ float cm_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
             stage_rows(pre);
             if (tile + 1 < tile1) fetch_rows(feats, tp0 + 2 * TT + 1 + wave, pre);      // next tile's rows, one tile ahead
             block1_row((tp0 + 1 + wave) % NR);
-            __syncthreads();
+            cm_lds_barrier();
             // ---- block 2: implicit GEMM, 16 positions x 32 channels per wave
             if (wave < NB) {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
                 *reinterpret_cast<float4 *>(o) = make_float4(acc0[0] + bias2[0].x, acc0[1] + bias2[0].y, acc0[2] + bias2[0].z, acc0[3] + bias2[0].w);
                 *reinterpret_cast<float4 *>(o + 16) = make_float4(acc1[0] + bias2[1].x, acc1[1] + bias2[1].y, acc1[2] + bias2[1].z, acc1[3] + bias2[1].w);
             }
-            __syncthreads();
+            cm_lds_barrier();
             // ---- LayerNorm over (freq, channel) + LeakyReLU, one wave per output step
             if (wave < TT && r0 + wave < T2) {
                 constexpr int nfeat = F2 * C2;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
                 }
             }
             // the next tile overwrites 8 of the 9 row slots and ot: everyone must be done reading them
-            __syncthreads();
+            cm_lds_barrier();
         }
     }
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 4) void conv_xproj_kernel(const cm_conv_xproj_
             __builtin_amdgcn_raw_buffer_store_b64(pb, br, c0 * 2, (ts + i) * yb_ts, 0);
         }
     }
-    __syncthreads();
+    cm_lds_barrier();                                             // the u stores to HBM stay in flight under phase 2
 
     // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]; one wave per direction (48 MFMAs)
     if (wave >= 2) return;

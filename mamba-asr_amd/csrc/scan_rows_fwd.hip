@@ -276,7 +276,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         tb += DIR * TB;
         if (k + 1 < nblk) produce(t_nxt, x_nxt, tb);
         if (more) commit(t_fill, x_fill);
-        if (ABL != 5) __syncthreads();
+        if (ABL != 5) cm_lds_barrier();                          // LDS-only: output stores and prefetch loads stay in flight
         const int t_old = t_cur, x_old = x_cur;
         t_cur = t_nxt; t_nxt = t_fill; t_fill = t_old;
         x_cur = x_nxt; x_nxt = x_fill; x_fill = x_old;
