@@ -174,7 +174,8 @@ def main():
         bytes_per_frame = {"conmamba_large_ctc": 168464, "conmamba_small_ctc": 74568,
                            "conmambamamba_large_s2s": 226564}.get(a.config)
         line = {
-            "metric": "encoder audio-frames/sec (ConMamba-large, L=4000)", "value": round(value, 1),
+            "metric": ("encoder audio-frames/sec (ConMamba-large, L=4000)" if (a.config, a.frames) == ("conmamba_large_ctc", 4000)
+                       else f"encoder audio-frames/sec ({a.config}, L={a.frames})"), "value": round(value, 1),
             "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",

@@ -56,6 +56,11 @@ int         cm_scan_num_chunks(int seqlen);
  * 0 restores the automatic choice (also settable with the CM_SCAN_SPLIT environment variable).
  * Returns the previous value.  Process-wide; meant for tests and benchmarks. */
 int         cm_scan_set_split(int lanes_per_channel);
+/* Timing-only ablation switch of the scan kernels (0 = product kernel; 1..5 select builds with one stage removed, see
+ * csrc/scan_rows_fwd.hip / scan_cl_fwd.hip; results are then WRONG by construction).  Returns the previous value.
+ * Process-wide; used by tools/bench_scan.py to produce the ablation table in DESIGN.md. */
+int         cm_debug_set(int ablation);
+int         cm_debug_get(void);
 
 /* ---------------------------------------------------------------------------------------
  * Selective scan forward — replaces selective_scan_cuda.fwd

@@ -185,6 +185,8 @@ SYMBOLS = [
     ("cm_selective_scan_bwd", C.c_int, [C.POINTER(ScanBwdArgs)]),
     ("cm_causal_conv1d_fwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
+    ("cm_debug_set", C.c_int, [C.c_int]),
+    ("cm_debug_get", C.c_int, []),
     ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
