@@ -310,6 +310,34 @@ typedef struct cm_glu_dwconv_args {
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
 
 /* ---------------------------------------------------------------------------------------
+ * Depthwise Conv1d over time, forward and backward, on the module API's (batch, dim, seqlen) time-contiguous layout:
+ * the ConvolutionModule's depthwise stage (reference modules/Conmamba.py:271-284, called at :443; nn.Conv1d with
+ * groups = dim, stride 1, zero padding).  Output length = seqlen.
+ *   y[b,c,t]  = bias[c] + sum_k weight[c,k] * x[b,c,t + k - pad_left]        (x = 0 outside [0, seqlen))
+ *   dx[b,c,s] = sum_k weight[c,k] * dy[b,c,s - k + pad_left]
+ *   dweight[c,k] += sum_{b,t} dy[b,c,t] * x[b,c,t + k - pad_left];   dbias[c] += sum_{b,t} dy[b,c,t]
+ * pad_left = ksize/2 for 'same' padding, ksize-1 for the causal variant (padding then chomp, :445-446).
+ * ksize <= 32.  dweight / dbias are fp32 and accumulated into (caller zero-initialises); deterministic (no atomics).
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_dwconv1d_args {
+    int32_t batch, dim, seqlen, ksize, pad_left;
+    int32_t io_dtype;            /* CM_BF16 or CM_F32: x, y, dy, dx                     */
+    const void  *x;
+    const float *weight;         /* (dim, ksize)                                        */
+    const float *bias;           /* (dim) or NULL                                       */
+    void        *y;              /* forward only                                        */
+    const void  *dy;             /* backward only                                       */
+    void        *dx;
+    float       *dweight;        /* (dim, ksize)                                        */
+    float       *dbias;          /* (dim) or NULL                                       */
+    int64_t x_bs, x_ds, y_bs, y_ds, dy_bs, dy_ds, dx_bs, dx_ds;   /* batch / channel strides in elements */
+    void *stream;
+} cm_dwconv1d_args;
+
+int cm_dwconv1d_fwd(const cm_dwconv1d_args *args);
+int cm_dwconv1d_bwd(const cm_dwconv1d_args *args);
+
+/* ---------------------------------------------------------------------------------------
  * Mixer -> convolution-module seam in one kernel (bf16 GEMM operands, d_model 256):
  *   x_out = x + alpha * y;  h = LayerNorm(x_out; ln_g, ln_b, eps);  pw = h @ W^T + bias  (W: (2*dim, dim));
  *   out = pw[:, :dim] * sigmoid(pw[:, dim:])                  (reference modules/Conmamba.py:639-640, 441-443)

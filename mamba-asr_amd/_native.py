@@ -92,6 +92,15 @@ class ConvXprojArgs(C.Structure):
     ]
 
 
+class Dwconv1dArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("seqlen", i32), ("ksize", i32), ("pad_left", i32), ("io_dtype", i32),
+        ("x", vp), ("weight", fp), ("bias", fp), ("y", vp), ("dy", vp), ("dx", vp), ("dweight", fp), ("dbias", fp),
+        ("x_bs", i64), ("x_ds", i64), ("y_bs", i64), ("y_ds", i64), ("dy_bs", i64), ("dy_ds", i64), ("dx_bs", i64), ("dx_ds", i64),
+        ("stream", vp),
+    ]
+
+
 class LnPwGluArgs(C.Structure):
     _fields_ = [
         ("rows", i32), ("dim", i32), ("x", fp), ("y", vp), ("ln_g", fp), ("ln_b", fp), ("w", vp), ("bias", fp),
@@ -193,6 +202,8 @@ SYMBOLS = [
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_ln_pw_glu", C.c_int, [C.POINTER(LnPwGluArgs)]),
+    ("cm_dwconv1d_fwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
+    ("cm_dwconv1d_bwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),
     ("cm_cnn_block2", C.c_int, [C.POINTER(CnnBlock2Args)]),
     ("cm_cnn_front", C.c_int, [C.POINTER(CnnFrontArgs)]),

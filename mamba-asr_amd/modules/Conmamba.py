@@ -16,12 +16,19 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
+from .. import ops
 from ..sb_compat import LayerNorm, PositionalwiseFeedForward, Swish
 from .mamba.bimamba import Mamba as BiMamba
 from .mamba.bimamba import UniMamba as Mamba
 
 FFN_RESIDUAL_SCALE = 0.5          # reference ConMambaConstants :161
 FINAL_NORM_EPS = 1e-6             # reference ConMambaConstants :166
+
+
+# depthwise stage of the ConvolutionModule on cm_dwconv1d_fwd / _bwd when on the GPU; CM_NATIVE_DWCONV=0 = nn.Conv1d
+USE_NATIVE_DWCONV = os.environ.get("CM_NATIVE_DWCONV", "1") == "1"
 
 
 class ConvolutionModule(nn.Module):
@@ -46,10 +53,17 @@ class ConvolutionModule(nn.Module):
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
         if dynchunktrain_config is not None:
             raise NotImplementedError("dynamic chunk training is not used on the ConMamba path")
-        out = self.layer_norm(x).transpose(1, 2)
-        out = self.conv(self.bottleneck(out))
-        if self.causal:
-            out = out[..., : -self.padding]
+        out = self.bottleneck(self.layer_norm(x).transpose(1, 2))
+        if out.is_cuda and USE_NATIVE_DWCONV and self.dilation == 1 and self.kernel_size <= 32 \
+                and out.dtype in (torch.bfloat16, torch.float32):
+            # native depthwise conv forward/backward (cm_dwconv1d_*): 'same' zero padding, or all padding in front for the
+            # causal variant (= the reference's pad-then-chomp)
+            out = ops.DepthwiseConv1dFn.apply(out, self.conv.weight, self.conv.bias,
+                                              self.kernel_size - 1 if self.causal else self.kernel_size // 2)
+        else:
+            out = self.conv(out)
+            if self.causal:
+                out = out[..., : -self.padding]
         out = self.after_conv(out.transpose(1, 2))
         if mask is not None:
             out.masked_fill_(mask, 0.0)

@@ -401,6 +401,64 @@ def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_
     return x_out, out
 
 
+def _dwconv_args(x, weight, bias, pad_left):
+    _dev_check(x, weight, bias)
+    x = _time_contig(x)
+    if x.dim() != 3:
+        raise RuntimeError("dwconv1d: x must be (batch, dim, seqlen)")
+    w = _f32c(weight).reshape(x.shape[1], -1)
+    bs = _f32c(bias)
+    a = N.Dwconv1dArgs()
+    a.batch, a.dim, a.seqlen, a.ksize, a.pad_left, a.io_dtype = x.shape[0], x.shape[1], x.shape[2], w.shape[1], int(pad_left), _DT[x.dtype]
+    a.x, a.weight, a.bias, a.x_bs, a.x_ds = _ptr(x), _ptr(w), _ptr(bs), x.stride(0), x.stride(1)
+    a.stream = _stream()
+    return a, x, w, bs
+
+
+def dwconv1d_fwd(x, weight, bias=None, pad_left=None):
+    """Depthwise Conv1d over time (cm_dwconv1d_fwd): x (batch, dim, seqlen), weight (dim, 1, k) or (dim, k), zero
+    padding with ``pad_left`` zeros in front (default k // 2 = 'same'); returns y of the same shape."""
+    k = weight.shape[-1]
+    a, x, w, bs = _dwconv_args(x, weight, bias, k // 2 if pad_left is None else pad_left)
+    y = torch.empty_like(x, memory_format=torch.contiguous_format)
+    a.y, a.y_bs, a.y_ds = _ptr(y), y.stride(0), y.stride(1)
+    _launch("cm_dwconv1d_fwd", N.lib().cm_dwconv1d_fwd, a, units=x.shape[0] * x.shape[2])
+    return y
+
+
+def dwconv1d_bwd(x, weight, dy, has_bias=True, pad_left=None):
+    """-> (dx, dweight (dim, k) fp32, dbias (dim) fp32 or None) of dwconv1d_fwd (cm_dwconv1d_bwd)."""
+    k = weight.shape[-1]
+    a, x, w, _ = _dwconv_args(x, weight, None, k // 2 if pad_left is None else pad_left)
+    _dev_check(dy)
+    dy = _time_contig(dy)
+    if dy.dtype != x.dtype or dy.shape != x.shape:
+        raise RuntimeError("dwconv1d_bwd: dy must match x in shape and dtype")
+    dx = torch.empty_like(x, memory_format=torch.contiguous_format)
+    dw = torch.zeros_like(w)
+    db = torch.zeros((x.shape[1],), dtype=torch.float32, device=x.device) if has_bias else None
+    a.dy, a.dy_bs, a.dy_ds, a.dx, a.dx_bs, a.dx_ds = _ptr(dy), dy.stride(0), dy.stride(1), _ptr(dx), dx.stride(0), dx.stride(1)
+    a.dweight, a.dbias = _ptr(dw), _ptr(db)
+    _launch("cm_dwconv1d_bwd", N.lib().cm_dwconv1d_bwd, a, units=x.shape[0] * x.shape[2])
+    return dx, dw, db
+
+
+class DepthwiseConv1dFn(torch.autograd.Function):
+    """autograd node over cm_dwconv1d_fwd / _bwd (drop-in for the depthwise nn.Conv1d of the ConvolutionModule)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad_left):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.pad_left = bias is not None, pad_left
+        return dwconv1d_fwd(x, weight, bias, pad_left)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = dwconv1d_bwd(x, weight, dy.to(x.dtype), ctx.has_bias, ctx.pad_left)
+        return dx, dw.reshape(weight.shape).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
+
+
 def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
     """Mixer -> convolution-module seam (cm_ln_pw_glu): x_out = x + alpha*y; g = GLU(LayerNorm(x_out) @ W^T + bias).
     x (rows, 256) fp32 contiguous; y (rows, 256) bf16 or None; norm = (weight, bias, eps); w: PackedWeight of the

@@ -310,6 +310,37 @@ def test_conv_xproj(ops, shape):
         close(xdbl[:, :, 48 * i:48 * (i + 1)].float(), want, 1.6e-2, 2e-2)
 
 
+@pytest.mark.parametrize("shape,k,causal", [((2, 48, 250), 31, False), ((3, 256, 1000), 31, False), ((2, 17, 37), 31, True),
+                                            ((1, 8, 2500), 15, False), ((2, 144, 5), 31, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv1d_forward_backward(ops, shape, k, causal, dtype):
+    """cm_dwconv1d_fwd / _bwd (through the autograd node the ConvolutionModule uses) vs torch's depthwise conv1d and its
+    autograd in float64 on the CPU: 'same' padding and the causal pad-then-chomp variant, rows longer than one pass
+    (2500 steps), rows shorter than the kernel (5 steps), channel counts that are not multiples of anything."""
+    b, d, l = shape
+    gen = torch.Generator().manual_seed(l + d + k)
+    x = torch.randn(b, d, l, generator=gen).to(dtype)
+    w = torch.randn(d, 1, k, generator=gen) / k ** 0.5
+    bias = torch.randn(d, generator=gen) * 0.1
+    dy = torch.randn(b, d, l, generator=gen).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    pad = k - 1 if causal else k // 2
+    ref = torch.nn.functional.conv1d(xr, wr, br, padding=pad, groups=d)
+    ref = ref[..., :l] if causal else ref
+    ref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    got = ops.DepthwiseConv1dFn.apply(xg, wg, bg, pad)
+    got.backward(dy.to(DEV))
+    ft, gt = ((1e-5, 1e-5), (1e-4, 1e-4)) if dtype == torch.float32 else ((1.6e-2, 1e-2), (2e-2, 2e-2))
+    close(got.float(), ref, *ft)
+    close(xg.grad.float(), xr.grad, *gt)
+    scale = max(1.0, wr.grad.abs().max().item())
+    close(wg.grad, wr.grad, gt[0], gt[1] * scale)
+    close(bg.grad, br.grad, gt[0], gt[1] * max(1.0, br.grad.abs().max().item()))
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
