@@ -20,6 +20,7 @@
 // x_dbl is read as the x_proj GEMM wrote it: rows (batch*time, [dt(16, zero padded) | B(16) | C(16)]) in the I/O dtype —
 // no transposed copy, no fp32 staging buffer.
 #include "cm_common.h"
+#include <type_traits>
 
 extern "C" int cm_debug_get();
 
@@ -155,7 +156,8 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
 
     // delta' = softplus(W_dt . dt + bias), delta'*u for the block staged at (buf_tile, buf_x) -> per-wave patch;
     // owned (u, z) -> registers.  tb = the block's base step.
-    auto produce = [&](const int buf_tile, const int buf_x, const int tb) {
+    auto produce_impl = [&](const int buf_tile, const int buf_x, const int tb, auto ragged_tag) {
+        constexpr bool ragged = decltype(ragged_tag)::value;      // only the sequence's last block has padded steps
         const float *xt = reinterpret_cast<const float *>(lds + L::kX + buf_x);
         // A operand: lane (m = step = lane%16, k = lane/16) holds dt[step][4k + q]
         const f32x4 dtf = *reinterpret_cast<const f32x4 *>(xt + c16 * XS + 4 * g);
@@ -167,7 +169,6 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         // acc[i] = delta_raw[step 4g+i][channel c16]
         const IO *ut = reinterpret_cast<const IO *>(lds + L::kU + buf_tile) + 16 * w + c16 + 4 * g * 64;
         const IO *zt = reinterpret_cast<const IO *>(lds + L::kZ + buf_tile) + 16 * w + c16 + 4 * g * 64;
-        const bool ragged = tb + TB > T;                          // uniform: only the last block of the sequence
         float o[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -182,6 +183,11 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         }
         *reinterpret_cast<f32x4 *>(pww + 8 * g) = f32x4{o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f32x4 *>(pww + 8 * g + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    };
+
+    auto produce = [&](const int buf_tile, const int buf_x, const int tb) {
+        if (tb + TB > T) produce_impl(buf_tile, buf_x, tb, std::true_type{});      // uniform branch: the selects that zero
+        else produce_impl(buf_tile, buf_x, tb, std::false_type{});                // padded steps stay out of the common path
     };
 
     // 16 recurrence steps on the block staged at buf_x; y[step][channel] accumulated by the matrix pipe.
