@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 4)")
+    ap.add_argument("--stream-mode", choices=["join", "free"], default=None,
+                    help="join (default): the scan runs once per layer on the whole batch; free: fully independent parts")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=64, help="utterances in the CPU-baseline sample")
     return ap.parse_args()
@@ -93,6 +96,11 @@ def main():
     from mamba_asr_amd import ops
     from mamba_asr_amd.asr import CONFIGS, ConMambaASR, samples_for_frames, synthetic_wavs
 
+    from mamba_asr_amd import fused
+    if a.streams is not None:
+        fused.N_STREAMS = a.streams
+    if a.stream_mode is not None:
+        fused.STREAM_MODE = a.stream_mode
     cfg = CONFIGS[a.config]
     model = ConMambaASR(cfg).to(dev).eval()
     wavs, lens = synthetic_wavs(a.batch, samples_for_frames(a.frames), cfg.seed + rank, dev)
@@ -183,7 +191,8 @@ def main():
                                    f"({a.frames // 4} scan steps) per GPU, random-init weights",
                        "global_batch": world * a.batch, "frames_per_utterance": a.frames,
                        "parallelism": f"utterance shards x{world} (no collective in forward)",
-                       "launch": "eager" if a.no_graph else "hipGraph replay"},
+                       "launch": "eager" if a.no_graph else "hipGraph replay",
+                       "streams": f"{fused.N_STREAMS} ({fused.STREAM_MODE})"},
             "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
             "roofline": roof, "cpu_baseline": base,
         }
