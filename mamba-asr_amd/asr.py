@@ -95,6 +95,22 @@ class ConMambaASR(nn.Module):
         enc = self.encode(wavs, wav_lens, epoch, augment)
         return torch.log_softmax(self.ctc_lin(enc), dim=-1)
 
+    def forward_s2s(self, wavs, wav_lens, tokens_bos, epoch=0, augment=None, pad_idx=0):
+        """train_S2S.py:285-320: features -> CNN -> Transformer(src, <bos> tokens) -> (p_ctc over encoder steps,
+        p_seq over decoder steps), both log-probabilities."""
+        assert self.cfg.num_decoder_layers > 0, "forward_s2s needs a decoder (S2S configuration)"
+        src = self.CNN(self.features(wavs, wav_lens, epoch, augment))
+        enc_out, pred = self.Transformer(src, tokens_bos, wav_lens, pad_idx=pad_idx)
+        return torch.log_softmax(self.ctc_lin(enc_out), dim=-1), torch.log_softmax(self.seq_lin(pred), dim=-1)
+
+    def s2s_objective(self, p_ctc, p_seq, tokens, tokens_lens, tokens_eos, tokens_eos_lens, wav_lens, ctc_weight=0.3,
+                      label_smoothing=0.1, pad_idx=0):
+        """train_S2S.py:518-529: ctc_weight * CTC(p_ctc, tokens) + (1 - ctc_weight) * label-smoothed KL(p_seq, tokens_eos)."""
+        loss_seq = sb.kldiv_loss(p_seq, tokens_eos, length=tokens_eos_lens, label_smoothing=label_smoothing, pad_idx=pad_idx,
+                                 reduction="batchmean")
+        loss_ctc = sb.ctc_loss(p_ctc, tokens, wav_lens, tokens_lens, self.cfg.blank_index, reduction="batchmean")
+        return ctc_weight * loss_ctc + (1.0 - ctc_weight) * loss_seq
+
     def ctc_objective(self, p_ctc, tokens, wav_lens, tokens_lens):
         """train_CTC.py:405 with loss_reduction batchmean."""
         return sb.ctc_loss(p_ctc, tokens, wav_lens, tokens_lens, self.cfg.blank_index, reduction="batchmean")

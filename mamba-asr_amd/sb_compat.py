@@ -281,6 +281,36 @@ def ctc_loss(log_probs, targets, input_lens, target_lens, blank_index, reduction
     return loss
 
 
+def kldiv_loss(log_probs, targets, length=None, label_smoothing=0.0, pad_idx=0, reduction="mean"):
+    """speechbrain.nnet.losses.kldiv_loss as the S2S recipes call it (reference hparams/S2S/conmambamamba_large.yaml
+    `seq_cost` with label_smoothing 0.1, reduction batchmean; train_S2S.py:518-529): label-smoothed KL divergence
+    between log-probabilities (batch, steps, classes) and integer targets (batch, steps); target distribution =
+    1 - label_smoothing on the target class, label_smoothing / (classes - 1) elsewhere; padded steps (target ==
+    pad_idx) contribute nothing; 'batchmean' = sum / batch.  (speechbrain is absent: restated semantics, parity unpinned.)"""
+    if log_probs.dim() == 2:
+        log_probs = log_probs.unsqueeze(1)
+    bz, steps, n_class = log_probs.shape
+    flat = log_probs.reshape(-1, n_class).float()
+    tgt = targets.reshape(-1).long().detach()
+    ignore = tgt == pad_idx
+    if label_smoothing > 0:
+        with torch.no_grad():
+            true_dist = torch.full_like(flat, label_smoothing / (n_class - 1))
+            true_dist.scatter_(1, tgt.masked_fill(ignore, 0).unsqueeze(1), 1.0 - label_smoothing)
+        loss = F.kl_div(flat, true_dist, reduction="none")
+    else:
+        loss = F.nll_loss(flat, tgt.masked_fill(ignore, 0), reduction="none").unsqueeze(1)
+    loss = loss.masked_fill(ignore.unsqueeze(1), 0.0)
+    if reduction == "batchmean":
+        return loss.sum() / bz
+    if reduction == "sum":
+        return loss.sum()
+    if reduction == "batch":
+        per = loss.view(bz, -1).sum(1)
+        return per / (length * steps if length is not None else steps)
+    return loss.sum() / max(int((~ignore).sum()), 1)
+
+
 class NoamScheduler:
     """speechbrain.nnet.schedulers.NoamScheduler: lr = lr0 * sqrt(warm) * min(step^-0.5, step * warm^-1.5)."""
 
