@@ -310,6 +310,48 @@ typedef struct cm_glu_dwconv_args {
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);
 
 /* ---------------------------------------------------------------------------------------
+ * Single-step (decode-time) updates of a Mamba mixer: the two calls of bimamba.Mamba.step (reference
+ * modules/mamba/bimamba.py:320-365).  All tensors contiguous; states are fp32 and updated IN PLACE.
+ *   cm_causal_conv1d_update (causal_conv1d.causal_conv1d_update, :337-343 / fallback :331-336):
+ *     conv_state (batch, dim, width) <- shifted left by one with x (batch, dim) appended;
+ *     out[b,c] = [silu](bias[c] + sum_k weight[c,k] * conv_state[b,c,k])
+ *   cm_selective_state_update (mamba_ssm selective_state_update, :360-362 / fallback :350-358):
+ *     dt' = [softplus](dt + dt_bias);  state[b,c,n] <- state * exp(dt' * A[c,n]) + dt' * B[b,n] * x[b,c];
+ *     out[b,c] = (sum_n state[b,c,n] * C[b,n] + D[c] * x[b,c]) * [silu(z[b,c])]
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_conv_update_args {
+    int32_t batch, dim, width;
+    int32_t io_dtype;            /* x, out                                          */
+    int32_t silu;
+    int32_t pad_;
+    const void  *x;              /* (batch, dim)                                    */
+    float       *conv_state;     /* (batch, dim, width) fp32, in place              */
+    const float *weight;         /* (dim, width)                                    */
+    const float *bias;           /* (dim) or NULL                                   */
+    void        *out;            /* (batch, dim)                                    */
+    void *stream;
+} cm_conv_update_args;
+
+typedef struct cm_state_update_args {
+    int32_t batch, dim, dstate;
+    int32_t io_dtype;            /* x, dt, B, C, z, out                             */
+    int32_t dt_softplus;
+    int32_t pad_;
+    float       *state;          /* (batch, dim, dstate) fp32, in place             */
+    const void  *x, *dt;         /* (batch, dim)                                    */
+    const float *A;              /* (dim, dstate)                                   */
+    const void  *B, *C;          /* (batch, dstate)                                 */
+    const float *D;              /* (dim) or NULL                                   */
+    const void  *z;              /* (batch, dim) or NULL                            */
+    const float *dt_bias;        /* (dim) or NULL                                   */
+    void        *out;            /* (batch, dim)                                    */
+    void *stream;
+} cm_state_update_args;
+
+int cm_causal_conv1d_update(const cm_conv_update_args *args);
+int cm_selective_state_update(const cm_state_update_args *args);
+
+/* ---------------------------------------------------------------------------------------
  * Depthwise Conv1d over time, forward and backward, on the module API's (batch, dim, seqlen) time-contiguous layout:
  * the ConvolutionModule's depthwise stage (reference modules/Conmamba.py:271-284, called at :443; nn.Conv1d with
  * groups = dim, stride 1, zero padding).  Output length = seqlen.

@@ -92,6 +92,21 @@ class ConvXprojArgs(C.Structure):
     ]
 
 
+class ConvUpdateArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("width", i32), ("io_dtype", i32), ("silu", i32), ("pad_", i32),
+        ("x", vp), ("conv_state", fp), ("weight", fp), ("bias", fp), ("out", vp), ("stream", vp),
+    ]
+
+
+class StateUpdateArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("dstate", i32), ("io_dtype", i32), ("dt_softplus", i32), ("pad_", i32),
+        ("state", fp), ("x", vp), ("dt", vp), ("A", fp), ("B", vp), ("C", vp), ("D", fp), ("z", vp), ("dt_bias", fp),
+        ("out", vp), ("stream", vp),
+    ]
+
+
 class Dwconv1dArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("dim", i32), ("seqlen", i32), ("ksize", i32), ("pad_left", i32), ("io_dtype", i32),
@@ -202,6 +217,8 @@ SYMBOLS = [
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),
     ("cm_ln_pw_glu", C.c_int, [C.POINTER(LnPwGluArgs)]),
+    ("cm_causal_conv1d_update", C.c_int, [C.POINTER(ConvUpdateArgs)]),
+    ("cm_selective_state_update", C.c_int, [C.POINTER(StateUpdateArgs)]),
     ("cm_dwconv1d_fwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
     ("cm_dwconv1d_bwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),

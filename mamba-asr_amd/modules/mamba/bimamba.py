@@ -170,9 +170,31 @@ class UniMamba(nn.Module):
         self.D._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **fk)
 
+    def allocate_inference_cache(self, batch_size, max_seqlen=None, dtype=None, **kwargs):
+        """(conv_state (batch, d_inner, d_conv), ssm_state (batch, d_inner, d_state)), zero, fp32 (reference :367-383)."""
+        dev = self.in_proj.weight.device
+        return (torch.zeros(batch_size, self.d_inner, self.d_conv, device=dev, dtype=torch.float32),
+                torch.zeros(batch_size, self.d_inner, self.d_state, device=dev, dtype=torch.float32))
+
+    def step(self, hidden_states, conv_state, ssm_state):
+        """One decoding step (reference bimamba.py:320-365): hidden_states (batch, 1, d_model) -> (out (batch, 1,
+        d_model), conv_state, ssm_state); both states are updated in place by cm_causal_conv1d_update /
+        cm_selective_state_update.  Feeding a sequence step by step from zero states reproduces ``forward``."""
+        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
+        from ... import ops
+        xz = self.in_proj(hidden_states.squeeze(1))                                     # (B, 2E)
+        x, z = xz.chunk(2, dim=-1)
+        x = ops.causal_conv1d_update(x, conv_state, self.conv1d.weight, self.conv1d.bias, silu=True)
+        x_db = self.x_proj(x)
+        dt, Bm, Cm = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight)                                          # bias is added in the kernel
+        y = ops.selective_state_update(ssm_state, x, dt, -torch.exp(self.A_log.float()), Bm, Cm, self.D.float(), z=z,
+                                       dt_bias=self.dt_proj.bias.float(), dt_softplus=True)
+        return self.out_proj(y).unsqueeze(1), conv_state, ssm_state
+
     def forward(self, hidden_states, inference_params=None):
         if inference_params is not None:
-            raise NotImplementedError("stateful decoding has no HIP kernel yet")
+            raise NotImplementedError("inference_params caches are not used by the ConMamba recipes: call step()")
         batch, seqlen, _ = hidden_states.shape
         xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen)
         xz = xz.transpose(0, 1)

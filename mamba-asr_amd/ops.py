@@ -401,6 +401,42 @@ def add_layernorm(x, y=None, alpha=1.0, norm1=None, norm2=None, x_out=None, out_
     return x_out, out
 
 
+def causal_conv1d_update(x, conv_state, weight, bias=None, silu=True):
+    """Decode-time conv step (cm_causal_conv1d_update; reference bimamba.py:331-343): conv_state (batch, dim, width) fp32 is
+    shifted and gets x (batch, dim) appended IN PLACE; returns out (batch, dim) in x's dtype."""
+    _dev_check(x, conv_state, weight, bias)
+    if conv_state.dtype != torch.float32 or not conv_state.is_contiguous():
+        raise RuntimeError("causal_conv1d_update: conv_state must be a contiguous fp32 (batch, dim, width) tensor")
+    x = x.contiguous()
+    w, bs = _f32c(weight).reshape(conv_state.shape[1], -1), _f32c(bias)
+    out = torch.empty_like(x)
+    a = N.ConvUpdateArgs()
+    a.batch, a.dim, a.width, a.io_dtype, a.silu = x.shape[0], x.shape[1], conv_state.shape[2], _DT[x.dtype], int(bool(silu))
+    a.x, a.conv_state, a.weight, a.bias, a.out, a.stream = _ptr(x), _ptr(conv_state), _ptr(w), _ptr(bs), _ptr(out), _stream()
+    _launch("cm_causal_conv1d_update", N.lib().cm_causal_conv1d_update, a, units=x.shape[0])
+    return out
+
+
+def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False):
+    """Decode-time SSM step (cm_selective_state_update; reference bimamba.py:350-362): state (batch, dim, dstate) fp32 is
+    updated IN PLACE; x, dt, z (batch, dim), B, C (batch, dstate) share one dtype; returns y (batch, dim)."""
+    _dev_check(state, x, dt, A, B, C, D, z, dt_bias)
+    if state.dtype != torch.float32 or not state.is_contiguous():
+        raise RuntimeError("selective_state_update: state must be a contiguous fp32 (batch, dim, dstate) tensor")
+    x = x.contiguous()
+    dt, B, C = dt.to(x.dtype).contiguous(), B.to(x.dtype).contiguous(), C.to(x.dtype).contiguous()
+    z = None if z is None else z.to(x.dtype).contiguous()
+    A, D, dt_bias = _f32c(A), _f32c(D), _f32c(dt_bias)
+    out = torch.empty_like(x)
+    a = N.StateUpdateArgs()
+    a.batch, a.dim, a.dstate, a.io_dtype, a.dt_softplus = x.shape[0], x.shape[1], state.shape[2], _DT[x.dtype], int(bool(dt_softplus))
+    a.state, a.x, a.dt, a.A, a.B, a.C, a.D, a.z, a.dt_bias, a.out = (_ptr(state), _ptr(x), _ptr(dt), _ptr(A), _ptr(B), _ptr(C), _ptr(D),
+                                                                     _ptr(z), _ptr(dt_bias), _ptr(out))
+    a.stream = _stream()
+    _launch("cm_selective_state_update", N.lib().cm_selective_state_update, a, units=x.shape[0])
+    return out
+
+
 def _dwconv_args(x, weight, bias, pad_left):
     _dev_check(x, weight, bias)
     x = _time_contig(x)

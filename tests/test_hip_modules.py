@@ -443,3 +443,25 @@ def test_ctc_loss_matches_oracle_within_1e3():
     print(f"CTC loss: oracle {float(ref):.5f}  gpu fp32 {float(loss32):.5f} (|delta| {d32:.2e})  gpu bf16 {float(lossbf):.5f} (|delta| {dbf:.2e})")
     assert d32 <= 1e-3
     assert dbf <= 5e-2 * max(1.0, abs(float(ref)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unimamba_step_reproduces_forward(dtype):
+    """Stateful single-step decode (reference bimamba.py:320-365): feeding a sequence token by token
+    through UniMamba.step (cm_causal_conv1d_update + cm_selective_state_update, states from allocate_inference_cache)
+    reproduces the full-sequence forward of the same mixer."""
+    from mamba_asr_amd.modules.mamba.bimamba import UniMamba
+    torch.manual_seed(4)
+    m = UniMamba(d_model=64, d_state=16, d_conv=4, expand=2).to(DEV).eval()
+    x = torch.randn(3, 21, 64, device=DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        full = m(x)
+        conv_state, ssm_state = m.allocate_inference_cache(3)
+        outs = []
+        for t in range(x.shape[1]):
+            o, conv_state, ssm_state = m.step(x[:, t:t + 1], conv_state, ssm_state)
+            outs.append(o)
+        stepped = torch.cat(outs, dim=1)
+    tol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(stepped.float(), full.float(), **tol)
+    assert conv_state.shape == (3, 128, 4) and ssm_state.shape == (3, 128, 16) and ssm_state.abs().max() > 0
