@@ -111,7 +111,7 @@ class Mamba(nn.Module):
         xz = xz.transpose(0, 1)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
-        xz = xz.contiguous()
+        # xz stays the (b, 2e, l) VIEW of the GEMM's (2e, b, l) output: time-contiguous, which is all the kernels need
         use_side = xz.is_cuda and not torch.is_grad_enabled()
         if use_side:
             # forward-only: the two directions share nothing but the input -> two HIP streams
@@ -128,7 +128,16 @@ class Mamba(nn.Module):
             out = self._direction(xz, backward=False)
             out_b = self._direction(xz, backward=True)
         mix = 0.5 * out + 0.5 * out_b if self.if_devide_out else out + out_b      # reference :250-253
-        y = F.linear(mix.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
+        # out / out_b are (b, e, l) views of (e, b, l) storage (selective_scan_interface._ebt), and so is mix: out_proj
+        # reads it as the transposed (e, b*l) matrix instead of copying it to (b, l, e)
+        mix_t = mix.permute(1, 0, 2)
+        if mix_t.is_contiguous():
+            w = self.out_proj.weight.to(mix.dtype) if torch.is_autocast_enabled("cuda") else self.out_proj.weight
+            y = torch.mm(mix_t.reshape(self.d_inner, batch * seqlen).t(), w.t()).view(batch, seqlen, -1)
+            if self.out_proj.bias is not None:
+                y = y + self.out_proj.bias.to(y.dtype)
+        else:
+            y = F.linear(mix.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
         if self.init_layer_scale is not None:
             y = y * self.gamma
         return y
@@ -201,7 +210,7 @@ class UniMamba(nn.Module):
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         A = -torch.exp(self.A_log.float())
-        return mamba_inner_fn(xz.contiguous(), self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+        return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                               self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
                               self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
 

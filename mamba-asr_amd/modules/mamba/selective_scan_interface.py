@@ -114,7 +114,19 @@ def _split_bc(x_dbl, rank, nstate, batch, length):
     return bc[0].unsqueeze(1), bc[1].unsqueeze(1)
 
 
+def _ebt(e, batch, length, like):
+    """(e, batch, length) storage and its (batch, e, length) time-contiguous view: every kernel takes batch / channel
+    strides, so tensors that a GEMM reads or writes as (e, batch*length) matrices never need a transposing copy."""
+    st = torch.empty((e, batch, length), dtype=like.dtype, device=like.device)
+    return st, st.transpose(0, 1)
+
+
 class _MambaInner(torch.autograd.Function):
+    """conv -> x_proj -> dt_proj -> selective scan [-> out_proj] with the reference's checkpointing (:171-229, 233-294).
+    The skinny GEMMs run in the (feature, batch*time) orientation on (feature, batch, time) storage whose
+    (batch, feature, time) views feed the HIP kernels: no transposing copies (the first version made ~10 per direction
+    per layer, forward + backward: 20 % of a training step)."""
+
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, out_proj_b, A, A_b, D, delta_bias,
@@ -128,84 +140,100 @@ class _MambaInner(torch.autograd.Function):
         rank, nstate = dt_proj_w.shape[1], A.shape[-1]
         w2 = conv_w.reshape(conv_w.shape[0], conv_w.shape[-1])                  # "d 1 w -> d w", :179
         x, z = xz[:, :e], xz[:, e:]
-        u = ops.causal_conv1d_fwd(x, w2, conv_b, True, reverse=reverse_time)    # K1, :182
-        x_dbl = F.linear(u.transpose(1, 2).reshape(batch * length, e), x_proj_w)           # :186
-        delta = (dt_proj_w @ x_dbl[:, :rank].t()).reshape(e, batch, length).transpose(0, 1).contiguous()   # :187
-        Bm, Cm = _split_bc(x_dbl, rank, nstate, batch, length)
+        u_s, u = _ebt(e, batch, length, xz)
+        ops.causal_conv1d_fwd(x, w2, conv_b, True, reverse=reverse_time, out=u)  # K1, :182
+        x_dblT = x_proj_w.to(u_s.dtype) @ u_s.view(e, batch * length)           # (rank + 2n, b*l) = x_dbl^T, :186
+        delta = (dt_proj_w.to(u_s.dtype) @ x_dblT[:rank]).view(e, batch, length).transpose(0, 1)   # :187, (b, e, l) view
+        Bm = x_dblT[rank:rank + nstate].view(nstate, batch, length).permute(1, 0, 2).unsqueeze(1)   # (b, 1, n, l) views
+        Cm = x_dblT[rank + nstate:].view(nstate, batch, length).permute(1, 0, 2).unsqueeze(1)
         need_x = any(t is not None and t.requires_grad for t in
                      (xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, A, A_b, D, delta_bias))
-        _, ck, out_z = ops.selective_scan_fwd(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                              reverse=reverse_time, need_out=False, need_x=need_x)   # K3, :218
+        oz_s, oz = _ebt(e, batch, length, xz)
+        _, ck, _ = ops.selective_scan_fwd(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse=reverse_time,
+                                          need_out=False, need_x=need_x, out_z_buf=oz)     # K3, :218
         ck_b = None
         if A_b is not None:                      # v1 bidirectional: second scan against time, summed (:504-512)
-            _, ck_b, oz_b = ops.selective_scan_fwd(u, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                                   reverse=not reverse_time, need_out=False, need_x=need_x)
-            out_z = out_z + oz_b
+            ozb_s, ozb = _ebt(e, batch, length, xz)
+            _, ck_b, _ = ops.selective_scan_fwd(u, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus,
+                                                reverse=not reverse_time, need_out=False, need_x=need_x, out_z_buf=ozb)
+            oz_s.add_(ozb_s)
         ctx.delta_softplus, ctx.checkpoint_lvl, ctx.reverse_time = delta_softplus, checkpoint_lvl, reverse_time
         ctx.has_out_proj, ctx.has_out_bias = out_proj_w is not None, out_proj_b is not None
         ctx.has_A_b = A_b is not None
         if checkpoint_lvl >= 1:                  # recompute conv output and delta in backward (:223-224)
-            u_s, delta_s = None, None
+            u_keep, delta_keep = None, None
         else:
-            u_s, delta_s = u, delta
-        ctx.save_for_backward(xz, w2, conv_b, x_dbl, x_proj_w, dt_proj_w, out_proj_w, u_s, delta_s, A, A_b, Bm, Cm,
-                              D, delta_bias, ck, ck_b)
+            u_keep, delta_keep = u_s, delta
+        ctx.save_for_backward(xz, w2, conv_b, x_dblT, x_proj_w, dt_proj_w, out_proj_w, u_keep, delta_keep, A, A_b, D,
+                              delta_bias, ck, ck_b)
         ctx.conv_w_shape = conv_w.shape
         if out_proj_w is None:
-            return out_z                                                        # (b, e, l), :229
-        return F.linear(out_z.transpose(1, 2), out_proj_w, out_proj_b)          # (b, l, d_model), :370
+            return oz                                                           # (b, e, l) view, :229
+        y = torch.mm(oz_s.view(e, batch * length).t(), out_proj_w.t())          # (b*l, d_model), :370
+        if out_proj_b is not None:
+            y = y + out_proj_b
+        return y.view(batch, length, -1)
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
-        (xz, w2, conv_b, x_dbl, x_proj_w, dt_proj_w, out_proj_w, u, delta, A, A_b, Bm, Cm, D, delta_bias, ck,
+        (xz, w2, conv_b, x_dblT, x_proj_w, dt_proj_w, out_proj_w, u_s, delta, A, A_b, D, delta_bias, ck,
          ck_b) = ctx.saved_tensors
         batch, two_e, length = xz.shape
         e = two_e // 2
         rank, nstate = dt_proj_w.shape[1], A.shape[-1]
-        rev = ctx.reverse_time
+        rev, bl = ctx.reverse_time, batch * length
         x, z = xz[:, :e], xz[:, e:]
         if ctx.checkpoint_lvl == 1:                                              # :243-246
-            u = ops.causal_conv1d_fwd(x, w2, conv_b, True, reverse=rev)
-            delta = (dt_proj_w @ x_dbl[:, :rank].t()).reshape(e, batch, length).transpose(0, 1).contiguous()
+            u_s, u = _ebt(e, batch, length, xz)
+            ops.causal_conv1d_fwd(x, w2, conv_b, True, reverse=rev, out=u)
+            delta = (dt_proj_w.to(u_s.dtype) @ x_dblT[:rank]).view(e, batch, length).transpose(0, 1)
+        else:
+            u = u_s.transpose(0, 1)
+        Bm = x_dblT[rank:rank + nstate].view(nstate, batch, length).permute(1, 0, 2).unsqueeze(1)
+        Cm = x_dblT[rank + nstate:].view(nstate, batch, length).permute(1, 0, 2).unsqueeze(1)
         dout_proj_w = dout_proj_b = None
         if ctx.has_out_proj:
-            dflat = dout.reshape(batch * length, -1)                             # (b l) d_model
-            dy = (dflat @ out_proj_w).reshape(batch, length, e).transpose(1, 2).contiguous()   # :392-393
+            dflat = dout.reshape(bl, -1)                                         # (b l) d_model
+            dy = (out_proj_w.t() @ dflat.t().to(out_proj_w.dtype)).view(e, batch, length).transpose(0, 1)   # :392-393
         else:
             dflat = None
             dy = dout if dout.stride(-1) == 1 else dout.contiguous()
+        dy = dy.to(u_s.dtype)
         dxz = torch.empty_like(xz)                                               # dx | dz side by side, :249-250
         dx, dz = dxz[:, :e], dxz[:, e:]
-        du, ddelta, dA, dB, dC, dD, dbias, _, out_z = ops.selective_scan_bwd(
+        du_s, du = _ebt(e, batch, length, xz)
+        dd_s, ddelta = _ebt(e, batch, length, xz)
+        oz_s, oz = _ebt(e, batch, length, xz) if ctx.has_out_proj else (None, None)
+        _, _, dA, dB, dC, dD, dbias, _, _ = ops.selective_scan_bwd(
             u, delta, A, Bm, Cm, D, z, delta_bias, dy, ck, ctx.delta_softplus, reverse=rev, dz=dz,
-            recompute_out_z=ctx.has_out_proj)                                    # K4, :252-256
+            recompute_out_z=ctx.has_out_proj, du_buf=du, ddelta_buf=ddelta, out_z_buf=oz)     # K4, :252-256
         dA_b = None
         if ctx.has_A_b:                                                          # :552-566
             du2, dd2, dA_b, dB2, dC2, dD2, dbias2, dz2, oz2 = ops.selective_scan_bwd(
                 u, delta, A_b, Bm, Cm, D, z, delta_bias, dy, ck_b, ctx.delta_softplus, reverse=not rev,
                 recompute_out_z=ctx.has_out_proj)
-            du, ddelta, dB, dC = du + du2, ddelta + dd2, dB + dB2, dC + dC2
+            du.add_(du2), ddelta.add_(dd2)
+            dB, dC = dB + dB2, dC + dC2
             dz.add_(dz2)
             dD = None if dD is None else dD + dD2
             dbias = None if dbias is None else dbias + dbias2
-            out_z = None if out_z is None else out_z + oz2
+            if oz is not None:
+                oz.add_(oz2)
         if ctx.has_out_proj:
-            dout_proj_w = dflat.t() @ out_z.transpose(1, 2).reshape(batch * length, e)         # :399
+            dout_proj_w = (oz_s.view(e, bl) @ dflat.to(oz_s.dtype)).t()          # :399
             if ctx.has_out_bias:
                 dout_proj_b = dflat.sum(0)                                       # :400
-        # gradients through the two skinny projections (:258-283)
-        dx_dbl = torch.empty_like(x_dbl)
-        dx_dbl[:, rank:rank + nstate] = dB[:, 0].permute(0, 2, 1).reshape(batch * length, nstate)
-        dx_dbl[:, rank + nstate:] = dC[:, 0].permute(0, 2, 1).reshape(batch * length, nstate)
-        dd_flat = ddelta.transpose(0, 1).reshape(e, batch * length)              # d (b l)
-        ddt_proj_w = dd_flat @ x_dbl[:, :rank]                                   # :278
-        dx_dbl[:, :rank] = dd_flat.t() @ dt_proj_w                               # :279
-        u_flat = u.transpose(1, 2).reshape(batch * length, e)
-        dx_proj_w = dx_dbl.t() @ u_flat                                          # :281
-        du_tot = du.transpose(1, 2).reshape(batch * length, e).addmm_(dx_dbl, x_proj_w)   # :282
-        du_tot = du_tot.reshape(batch, length, e).transpose(1, 2).contiguous()
-        _, dconv_w, dconv_b = ops.causal_conv1d_bwd(x, w2, conv_b, du_tot, True, reverse=rev, dx=dx)   # K2, :286
+        # gradients through the two skinny projections (:258-283), all on (feature, b*l) matrices
+        dx_dblT = torch.empty_like(x_dblT)
+        dx_dblT[rank:rank + nstate] = dB[:, 0].permute(1, 0, 2).reshape(nstate, bl)
+        dx_dblT[rank + nstate:] = dC[:, 0].permute(1, 0, 2).reshape(nstate, bl)
+        dd_flat = dd_s.view(e, bl)
+        ddt_proj_w = dd_flat @ x_dblT[:rank].t()                                 # :278
+        dx_dblT[:rank] = dt_proj_w.t().to(dd_flat.dtype) @ dd_flat               # :279
+        dx_proj_w = dx_dblT @ u_s.view(e, bl).t()                                # :281
+        du_s.view(e, bl).addmm_(x_proj_w.t().to(du_s.dtype), dx_dblT)            # du + x_proj^T dx_dbl^T, :282
+        _, dconv_w, dconv_b = ops.causal_conv1d_bwd(x, w2, conv_b, du, True, reverse=rev, dx=dx)   # K2, :286
         return (dxz, dconv_w.reshape(ctx.conv_w_shape), dconv_b, dx_proj_w, ddt_proj_w, dout_proj_w, dout_proj_b,
                 dA, dA_b, dD, dbias, None, None, None)
 

@@ -92,7 +92,7 @@ def _fill_scan_args(a, u, delta, A, B, C_, D, z, delta_bias, delta_softplus, rev
 
 
 def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
-                       reverse=False, need_out=True, need_x=True):
+                       reverse=False, need_out=True, need_x=True, out_z_buf: Optional[torch.Tensor] = None):
     """-> (out, x, out_z): what selective_scan_cuda.fwd returns (selective_scan_interface.py:42).
     ``out`` is the pre-gate output (None when z is given and need_out is False), ``x`` the
     checkpoint tensor (batch, dim, nchunks, 2*dstate) or None, ``out_z`` the gated output or None."""
@@ -108,16 +108,26 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     a = N.ScanFwdArgs()
     _fill_scan_args(a, u, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse)
     out = torch.empty((b, d, l), dtype=u.dtype, device=u.device) if (z is None or need_out) else None
-    out_z = torch.empty((b, d, l), dtype=u.dtype, device=u.device) if z is not None else None
+    out_z = None
+    if z is not None:
+        # out_z_buf: a pre-allocated time-contiguous (batch, dim, seqlen) view, e.g. of (dim, batch, seqlen) storage
+        out_z = out_z_buf if out_z_buf is not None else torch.empty((b, d, l), dtype=u.dtype, device=u.device)
+        if out_z.shape != (b, d, l) or out_z.stride(-1) != 1 or out_z.dtype != u.dtype:
+            raise RuntimeError("out_z_buf must be a time-contiguous (batch, dim, seqlen) tensor of u's dtype")
     x = torch.empty((b, d, num_chunks(l), 2 * A.shape[1]), dtype=torch.float32, device=u.device) if need_x else None
     a.out, a.out_z, a.x = _ptr(out), _ptr(out_z), _ptr(x)
     a.out_bs, a.out_ds = d * l, l
+    if out_z is not None:
+        if out is not None and (out_z.stride(0), out_z.stride(1)) != (d * l, l):
+            raise RuntimeError("out and a strided out_z_buf cannot be requested together (they share strides)")
+        a.out_bs, a.out_ds = out_z.stride(0), out_z.stride(1)
     _launch("cm_selective_scan_fwd", N.lib().cm_selective_scan_fwd, a, units=b * l)
     return out, x, out_z
 
 
 def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softplus=False, reverse=False,
-                       dz: Optional[torch.Tensor] = None, recompute_out_z=False):
+                       dz: Optional[torch.Tensor] = None, recompute_out_z=False, du_buf: Optional[torch.Tensor] = None,
+                       ddelta_buf: Optional[torch.Tensor] = None, out_z_buf: Optional[torch.Tensor] = None):
     """-> (du, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z): the tuple selective_scan_cuda.bwd
     returns (selective_scan_interface.py:67, 252).  ``dz`` may be a pre-allocated view (e.g. half of
     dxz, :249-256).  dB/dC are fp32 (batch, 1, dstate, seqlen)."""
@@ -133,12 +143,18 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
         raise RuntimeError("selective_scan_bwd needs the forward's checkpoint tensor x")
     a.fwd.x = _ptr(x)
     out_z = None
+    def _buf(t, what):                       # optional pre-allocated time-contiguous (batch, dim, seqlen) views
+        if t is None:
+            return torch.empty((b, d, l), dtype=u.dtype, device=u.device)
+        if t.shape != (b, d, l) or t.stride(-1) != 1 or t.dtype != u.dtype:
+            raise RuntimeError(f"{what} must be a time-contiguous (batch, dim, seqlen) tensor of u's dtype")
+        return t
     if z is not None and recompute_out_z:
-        out_z = torch.empty((b, d, l), dtype=u.dtype, device=u.device)
-        a.fwd.out_z, a.fwd.out_bs, a.fwd.out_ds = _ptr(out_z), d * l, l
+        out_z = _buf(out_z_buf, "out_z_buf")
+        a.fwd.out_z, a.fwd.out_bs, a.fwd.out_ds = _ptr(out_z), out_z.stride(0), out_z.stride(1)
     dev = u.device
-    du = torch.empty((b, d, l), dtype=u.dtype, device=dev)
-    ddelta = torch.empty((b, d, l), dtype=u.dtype, device=dev)
+    du = _buf(du_buf, "du_buf")
+    ddelta = _buf(ddelta_buf, "ddelta_buf")
     if z is not None and dz is None:
         dz = torch.empty((b, d, l), dtype=u.dtype, device=dev)
     if z is not None and dz.stride(-1) != 1:
@@ -150,7 +166,7 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
     dbias = torch.zeros((d,), dtype=torch.float32, device=dev) if delta_bias is not None else None
     a.dout, a.dout_bs, a.dout_ds = _ptr(dout), dout.stride(0), dout.stride(1)
     a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz if z is not None else None)
-    a.du_bs, a.du_ds, a.ddelta_bs, a.ddelta_ds = d * l, l, d * l, l
+    a.du_bs, a.du_ds, a.ddelta_bs, a.ddelta_ds = du.stride(0), du.stride(1), ddelta.stride(0), ddelta.stride(1)
     if z is not None:
         a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
     a.dA, a.dB, a.dC, a.dD, a.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias)
