@@ -379,6 +379,31 @@ typedef struct cm_dwconv1d_args {
 int cm_dwconv1d_fwd(const cm_dwconv1d_args *args);
 int cm_dwconv1d_bwd(const cm_dwconv1d_args *args);
 
+/* The same operator on CHANNELS-LAST rows (batch, seqlen, dim), channel axis contiguous, strides in elements: with it
+ * the ConvolutionModule stays in the (batch, time, channel) layout end to end (pointwise conv = GEMM on rows, GLU over
+ * the last axis), without transposing copies.  Same formulas as cm_dwconv1d_*.  The backward writes per-workgroup
+ * partial tap gradients to `partial` (cm_dwconv_cl_workspace_floats(batch, seqlen, dim) fp32, caller-owned) and sums
+ * them in a fixed order (deterministic); dweight / dbias are accumulated into. */
+typedef struct cm_dwconv_cl_args {
+    int32_t batch, dim, seqlen, ksize, pad_left;
+    int32_t io_dtype;
+    const void  *x;
+    const float *weight;         /* (dim, ksize) */
+    const float *bias;           /* (dim) or NULL */
+    void        *y;              /* forward only  */
+    const void  *dy;             /* backward only */
+    void        *dx;
+    float       *dweight;
+    float       *dbias;
+    float       *partial;        /* backward workspace */
+    int64_t x_bs, x_ts, y_bs, y_ts, dy_bs, dy_ts, dx_bs, dx_ts;
+    void *stream;
+} cm_dwconv_cl_args;
+
+int64_t cm_dwconv_cl_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);
+int cm_dwconv_cl_fwd(const cm_dwconv_cl_args *args);
+int cm_dwconv_cl_bwd(const cm_dwconv_cl_args *args);
+
 /* ---------------------------------------------------------------------------------------
  * Mixer -> convolution-module seam in one kernel (bf16 GEMM operands, d_model 256):
  *   x_out = x + alpha * y;  h = LayerNorm(x_out; ln_g, ln_b, eps);  pw = h @ W^T + bias  (W: (2*dim, dim));

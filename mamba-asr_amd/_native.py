@@ -116,6 +116,15 @@ class Dwconv1dArgs(C.Structure):
     ]
 
 
+class DwconvClArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("dim", i32), ("seqlen", i32), ("ksize", i32), ("pad_left", i32), ("io_dtype", i32),
+        ("x", vp), ("weight", fp), ("bias", fp), ("y", vp), ("dy", vp), ("dx", vp), ("dweight", fp), ("dbias", fp), ("partial", fp),
+        ("x_bs", i64), ("x_ts", i64), ("y_bs", i64), ("y_ts", i64), ("dy_bs", i64), ("dy_ts", i64), ("dx_bs", i64), ("dx_ts", i64),
+        ("stream", vp),
+    ]
+
+
 class LnPwGluArgs(C.Structure):
     _fields_ = [
         ("rows", i32), ("dim", i32), ("x", fp), ("y", vp), ("ln_g", fp), ("ln_b", fp), ("w", vp), ("bias", fp),
@@ -219,6 +228,9 @@ SYMBOLS = [
     ("cm_ln_pw_glu", C.c_int, [C.POINTER(LnPwGluArgs)]),
     ("cm_causal_conv1d_update", C.c_int, [C.POINTER(ConvUpdateArgs)]),
     ("cm_selective_state_update", C.c_int, [C.POINTER(StateUpdateArgs)]),
+    ("cm_dwconv_cl_workspace_floats", C.c_int64, [i32, i32, i32]),
+    ("cm_dwconv_cl_fwd", C.c_int, [C.POINTER(DwconvClArgs)]),
+    ("cm_dwconv_cl_bwd", C.c_int, [C.POINTER(DwconvClArgs)]),
     ("cm_dwconv1d_fwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
     ("cm_dwconv1d_bwd", C.c_int, [C.POINTER(Dwconv1dArgs)]),
     ("cm_cnn_block1", C.c_int, [C.POINTER(CnnBlock1Args)]),

@@ -53,17 +53,26 @@ class ConvolutionModule(nn.Module):
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
         if dynchunktrain_config is not None:
             raise NotImplementedError("dynamic chunk training is not used on the ConMamba path")
-        out = self.bottleneck(self.layer_norm(x).transpose(1, 2))
-        if out.is_cuda and USE_NATIVE_DWCONV and self.dilation == 1 and self.kernel_size <= 32 \
-                and out.dtype in (torch.bfloat16, torch.float32):
-            # native depthwise conv forward/backward (cm_dwconv1d_*): 'same' zero padding, or all padding in front for the
-            # causal variant (= the reference's pad-then-chomp)
-            out = ops.DepthwiseConv1dFn.apply(out, self.conv.weight, self.conv.bias,
-                                              self.kernel_size - 1 if self.causal else self.kernel_size // 2)
-        else:
-            out = self.conv(out)
-            if self.causal:
-                out = out[..., : -self.padding]
+        if x.is_cuda and USE_NATIVE_DWCONV and self.dilation == 1 and self.kernel_size <= 32:
+            # channels-last all the way: the pointwise conv (kernel 1) is a GEMM on (batch, time, channel) rows, GLU runs
+            # over the last axis and the depthwise conv + its autograd are cm_dwconv_cl_fwd / _bwd -- no transposing
+            # copies.  'same' zero padding, or all padding in front for the causal variant (= the reference's
+            # pad-then-chomp).
+            pw = self.bottleneck[0]
+            out = F.glu(F.linear(self.layer_norm(x), pw.weight.squeeze(-1), pw.bias), dim=-1)
+            if out.dtype in (torch.bfloat16, torch.float32):
+                out = ops.DepthwiseConvClFn.apply(out, self.conv.weight, self.conv.bias,
+                                                  self.kernel_size - 1 if self.causal else self.kernel_size // 2)
+            else:
+                out = self.conv(out.transpose(1, 2))
+                out = (out[..., : -self.padding] if self.causal else out).transpose(1, 2)
+            out = self.after_conv(out)
+            if mask is not None:
+                out.masked_fill_(mask, 0.0)
+            return out
+        out = self.conv(self.bottleneck(self.layer_norm(x).transpose(1, 2)))
+        if self.causal:
+            out = out[..., : -self.padding]
         out = self.after_conv(out.transpose(1, 2))
         if mask is not None:
             out.masked_fill_(mask, 0.0)

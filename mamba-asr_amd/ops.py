@@ -511,6 +511,64 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         return dx, dw.reshape(weight.shape).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
 
 
+def _dwconv_cl_args(x, weight, bias, pad_left):
+    _dev_check(x, weight, bias)
+    _rows_ok(x, "x")
+    w = _f32c(weight).reshape(x.shape[2], -1)
+    bs = _f32c(bias)
+    a = N.DwconvClArgs()
+    a.batch, a.seqlen, a.dim, a.ksize, a.pad_left, a.io_dtype = x.shape[0], x.shape[1], x.shape[2], w.shape[1], int(pad_left), _DT[x.dtype]
+    a.x, a.weight, a.bias, a.x_bs, a.x_ts = _ptr(x), _ptr(w), _ptr(bs), x.stride(0), x.stride(1)
+    a.stream = _stream()
+    return a, w, bs
+
+
+def dwconv_cl_fwd(x, weight, bias=None, pad_left=None):
+    """Depthwise Conv1d over time on channels-last rows (cm_dwconv_cl_fwd): x (batch, seqlen, dim), channel axis
+    contiguous; weight (dim, 1, k) or (dim, k); returns y (batch, seqlen, dim)."""
+    k = weight.shape[-1]
+    a, w, bs = _dwconv_cl_args(x, weight, bias, k // 2 if pad_left is None else pad_left)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    a.y, a.y_bs, a.y_ts = _ptr(y), y.stride(0), y.stride(1)
+    _launch("cm_dwconv_cl_fwd", N.lib().cm_dwconv_cl_fwd, a, units=x.shape[0] * x.shape[1])
+    return y
+
+
+def dwconv_cl_bwd(x, weight, dy, has_bias=True, pad_left=None):
+    """-> (dx, dweight (dim, k) fp32, dbias (dim) fp32 or None) of dwconv_cl_fwd (cm_dwconv_cl_bwd, deterministic)."""
+    k = weight.shape[-1]
+    a, w, _ = _dwconv_cl_args(x, weight, None, k // 2 if pad_left is None else pad_left)
+    _dev_check(dy)
+    if dy.stride(2) != 1:
+        dy = dy.contiguous()
+    if dy.dtype != x.dtype or dy.shape != x.shape:
+        raise RuntimeError("dwconv_cl_bwd: dy must match x in shape and dtype")
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dw = torch.zeros_like(w)
+    db = torch.zeros((x.shape[2],), dtype=torch.float32, device=x.device) if has_bias else None
+    part = torch.empty((N.lib().cm_dwconv_cl_workspace_floats(x.shape[0], x.shape[1], x.shape[2]),), dtype=torch.float32, device=x.device)
+    a.dy, a.dy_bs, a.dy_ts, a.dx, a.dx_bs, a.dx_ts = _ptr(dy), dy.stride(0), dy.stride(1), _ptr(dx), dx.stride(0), dx.stride(1)
+    a.dweight, a.dbias, a.partial = _ptr(dw), _ptr(db), _ptr(part)
+    _launch("cm_dwconv_cl_bwd", N.lib().cm_dwconv_cl_bwd, a, units=x.shape[0] * x.shape[1])
+    return dx, dw, db
+
+
+class DepthwiseConvClFn(torch.autograd.Function):
+    """autograd node over cm_dwconv_cl_fwd / _bwd: the ConvolutionModule's depthwise conv on (batch, time, channel) rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad_left):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.pad_left = bias is not None, pad_left
+        return dwconv_cl_fwd(x, weight, bias, pad_left)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = dwconv_cl_bwd(x, weight, dy.to(x.dtype), ctx.has_bias, ctx.pad_left)
+        return dx, dw.reshape(weight.shape).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
+
+
 def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
     """Mixer -> convolution-module seam (cm_ln_pw_glu): x_out = x + alpha*y; g = GLU(LayerNorm(x_out) @ W^T + bias).
     x (rows, 256) fp32 contiguous; y (rows, 256) bf16 or None; norm = (weight, bias, eps); w: PackedWeight of the

@@ -341,6 +341,38 @@ def test_dwconv1d_forward_backward(ops, shape, k, causal, dtype):
     close(bg.grad, br.grad, gt[0], gt[1] * max(1.0, br.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize("shape,k,causal", [((2, 250, 48), 31, False), ((3, 1000, 256), 31, False), ((2, 37, 17), 31, True),
+                                            ((1, 2500, 8), 15, False), ((2, 5, 144), 31, False), ((2, 130, 300), 31, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv_channels_last_forward_backward(ops, shape, k, causal, dtype):
+    """cm_dwconv_cl_fwd / _bwd (channels-last rows; the autograd node of the module-API ConvolutionModule) vs torch's
+    depthwise conv1d + autograd in float64: ragged tiles / runs, dim above and below one workgroup, causal padding; the
+    tap gradients are bit-identical between two runs (fixed-order reduction)."""
+    b, l, d = shape
+    gen = torch.Generator().manual_seed(l + d + k)
+    x = torch.randn(b, l, d, generator=gen).to(dtype)
+    w = torch.randn(d, 1, k, generator=gen) / k ** 0.5
+    bias = torch.randn(d, generator=gen) * 0.1
+    dy = torch.randn(b, l, d, generator=gen).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    pad = k - 1 if causal else k // 2
+    ref = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, br, padding=pad, groups=d)
+    ref = (ref[..., :l] if causal else ref).transpose(1, 2)
+    ref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    got = ops.DepthwiseConvClFn.apply(xg, wg, bg, pad)
+    got.backward(dy.to(DEV))
+    ft, gt = ((1e-5, 1e-5), (1e-4, 1e-4)) if dtype == torch.float32 else ((1.6e-2, 1e-2), (2e-2, 2e-2))
+    close(got.float(), ref, *ft)
+    close(xg.grad.float(), xr.grad, *gt)
+    close(wg.grad, wr.grad, gt[0], gt[1] * max(1.0, wr.grad.abs().max().item()))
+    close(bg.grad, br.grad, gt[0], gt[1] * max(1.0, br.grad.abs().max().item()))
+    _, dw2, db2 = ops.dwconv_cl_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), True, pad)
+    assert torch.equal(dw2.reshape(wg.grad.shape), wg.grad.float()) and torch.equal(db2, bg.grad.float())
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
