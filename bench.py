@@ -192,7 +192,7 @@ def main():
                        "global_batch": world * a.batch, "frames_per_utterance": a.frames,
                        "parallelism": f"utterance shards x{world} (no collective in forward)",
                        "launch": "eager" if a.no_graph else "hipGraph replay",
-                       "streams": f"{fused.N_STREAMS} ({fused.STREAM_MODE})"},
+                       "streams": f"{min(fused.N_STREAMS, max(1, a.batch // 16))} ({fused.STREAM_MODE})"},
             "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
             "roofline": roof, "cpu_baseline": base,
         }

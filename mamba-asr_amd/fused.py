@@ -391,7 +391,9 @@ def encoder_forward(encoder, src, dtype: Optional[torch.dtype] = None, streams: 
     """ConmambaEncoder.forward (eval, no grad) through the fused path: src (B, T, D) -> (B, T, D) fp32."""
     if dtype is None:
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
-    ns = N_STREAMS if streams is None else streams
+    # parts of at least 16 utterances (measured, join mode: 16 utterances 12.1 M frames/s as one part vs 10.6 M as four;
+    # 32: 15.1 / 15.3 / 15.2 M with 1 / 2 / 4; 64: 16.6 / 17.0 / 17.7 M); an explicit ``streams`` argument is taken as is
+    ns = min(N_STREAMS, max(1, src.shape[0] // 16)) if streams is None else streams
     if ns > 1 and src.shape[0] >= 2 * 8 and STREAM_MODE == "join":
         out = _encoder_forward_joined(encoder, src, dtype, ns)
         if out is not None:
