@@ -310,6 +310,30 @@ def test_conv_xproj(ops, shape):
         close(xdbl[:, :, 48 * i:48 * (i + 1)].float(), want, 1.6e-2, 2e-2)
 
 
+def test_scan_rows_extreme_time_steps(ops):
+    """Row-group scan at the edges of its arithmetic: time steps beyond softplus' linear threshold (delta = x for
+    x > 20), decays that underflow to zero (delta * A << -126 in exp2), negligible time steps (softplus' e^x branch) and
+    zero inputs -- against the fp64 oracle, all results finite."""
+    b, l, e = 2, 70, 64
+    gen = torch.Generator().manual_seed(99)
+    u = torch.randn(b, l, e, generator=gen)
+    z = torch.randn(b, l, e, generator=gen)
+    xd = torch.randn(b, l, 48, generator=gen)
+    xd[:, :, 16:32] *= 3.0
+    xd[0, 10:20] = 0.0                                           # a stretch of all-zero projections
+    Wdt = torch.randn(e, 16, generator=gen) * 0.3
+    A = -torch.exp(torch.randn(e, 16, generator=gen) * 2.0)      # |A| from 0.01 to 100
+    bias = torch.cat([torch.full((16,), 30.0), torch.full((16,), -25.0), torch.randn(32, generator=gen)])   # huge / tiny / normal steps
+    D = torch.randn(e, generator=gen)
+    delta = torch.einsum("er,blr->bel", Wdt.double(), xd[:, :, :16].double())
+    ref = O.selective_scan(u.transpose(1, 2), delta, A, xd[:, :, 16:32].transpose(1, 2), xd[:, :, 32:].transpose(1, 2), D,
+                           z.transpose(1, 2), bias, True, work_dtype=torch.float64).transpose(1, 2)
+    (got,) = ops.scan_cl_fwd([dict(u=u.to(DEV), A=A.to(DEV), D=D.to(DEV), delta_bias=bias.to(DEV),
+                                   dt_weight=ops.pad_dt_weight(Wdt.to(DEV)), xdbl=xd.to(DEV))], z=z.to(DEV))
+    assert torch.isfinite(got).all()
+    close(got, ref, 5e-4, 1e-4 * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("shape,k,causal", [((2, 48, 250), 31, False), ((3, 256, 1000), 31, False), ((2, 17, 37), 31, True),
                                             ((1, 8, 2500), 15, False), ((2, 144, 5), 31, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
