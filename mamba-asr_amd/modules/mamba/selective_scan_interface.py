@@ -229,9 +229,12 @@ class _MambaInner(torch.autograd.Function):
         dx_dblT[rank:rank + nstate] = dB[:, 0].permute(1, 0, 2).reshape(nstate, bl)
         dx_dblT[rank + nstate:] = dC[:, 0].permute(1, 0, 2).reshape(nstate, bl)
         dd_flat = dd_s.view(e, bl)
-        ddt_proj_w = dd_flat @ x_dblT[:rank].t()                                 # :278
+        # the two weight gradients reduce over b*l with a 16- / 48-wide output: as ONE GEMM with K = b*l the library runs
+        # them at ~170 us each (skinny output, no split-K); as per-utterance products summed over the batch they are
+        # bandwidth-bound reads of dd / u (strided batched GEMM on the (feature, batch, time) storage: no copies)
+        ddt_proj_w = torch.bmm(dd_s.permute(1, 0, 2), x_dblT[:rank].view(rank, batch, length).permute(1, 2, 0)).sum(0)   # :278
         dx_dblT[:rank] = dt_proj_w.t().to(dd_flat.dtype) @ dd_flat               # :279
-        dx_proj_w = dx_dblT @ u_s.view(e, bl).t()                                # :281
+        dx_proj_w = torch.bmm(dx_dblT.view(-1, batch, length).permute(1, 0, 2), u_s.permute(1, 2, 0)).sum(0)            # :281
         du_s.view(e, bl).addmm_(x_proj_w.t().to(du_s.dtype), dx_dblT)            # du + x_proj^T dx_dbl^T, :282
         _, dconv_w, dconv_b = ops.causal_conv1d_bwd(x, w2, conv_b, du, True, reverse=rev, dx=dx)   # K2, :286
         return (dxz, dconv_w.reshape(ctx.conv_w_shape), dconv_b, dx_proj_w, ddt_proj_w, dout_proj_w, dout_proj_b,
