@@ -19,7 +19,7 @@ import torch.nn.functional as F
 import os
 
 from .. import ops
-from ..sb_compat import LayerNorm, PositionalwiseFeedForward, Swish
+from ..sb_compat import LayerNorm, PositionalwiseFeedForward, RowsLinear, Swish, linear_rows
 from .mamba.bimamba import Mamba as BiMamba
 from .mamba.bimamba import UniMamba as Mamba
 
@@ -48,7 +48,7 @@ class ConvolutionModule(nn.Module):
         self.conv = nn.Conv1d(input_size, input_size, kernel_size=kernel_size, stride=1, padding=self.padding,
                               dilation=dilation, groups=input_size, bias=bias)
         self.after_conv = nn.Sequential(nn.LayerNorm(input_size), activation(),
-                                        nn.Linear(input_size, input_size, bias=bias), nn.Dropout(dropout))
+                                        RowsLinear(input_size, input_size, bias=bias), nn.Dropout(dropout))
 
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
         if dynchunktrain_config is not None:
@@ -59,7 +59,7 @@ class ConvolutionModule(nn.Module):
             # copies.  'same' zero padding, or all padding in front for the causal variant (= the reference's
             # pad-then-chomp).
             pw = self.bottleneck[0]
-            out = F.glu(F.linear(self.layer_norm(x), pw.weight.squeeze(-1), pw.bias), dim=-1)
+            out = F.glu(linear_rows(self.layer_norm(x), pw.weight.squeeze(-1), pw.bias), dim=-1)
             if out.dtype in (torch.bfloat16, torch.float32):
                 out = ops.DepthwiseConvClFn.apply(out, self.conv.weight, self.conv.bias,
                                                   self.kernel_size - 1 if self.causal else self.kernel_size // 2)

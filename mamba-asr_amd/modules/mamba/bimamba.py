@@ -23,6 +23,65 @@ from .selective_scan_interface import (bimamba_inner_fn, causal_conv1d_fn, mamba
                                        mamba_inner_fn_no_out_proj, selective_scan_fn)
 
 
+class _InProjFn(torch.autograd.Function):
+    """xz = in_proj(hidden) delivered as the (batch, 2e, seqlen) view of (2e, batch, seqlen) storage (reference
+    bimamba.py:192-198 without its rearrange copies); weight gradient per utterance + sum (see sb_compat._LinearRowsFn)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, hidden, weight):
+        batch, seqlen, _ = hidden.shape
+        ctx.save_for_backward(hidden, weight)
+        w = weight.to(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else weight
+        xz = (w @ hidden.reshape(batch * seqlen, -1).to(w.dtype).t()).reshape(-1, batch, seqlen)
+        return xz.transpose(0, 1)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dxz):
+        hidden, weight = ctx.saved_tensors
+        batch, seqlen, _ = hidden.shape
+        flat = dxz.permute(1, 0, 2).reshape(dxz.shape[1], batch * seqlen)       # a view when dxz has xz's layout
+        dh = dw = None
+        if ctx.needs_input_grad[0]:
+            dh = (flat.t() @ weight.to(flat.dtype)).view(batch, seqlen, -1)
+        if ctx.needs_input_grad[1]:
+            dw = torch.bmm(dxz, hidden.to(dxz.dtype)).sum(0)
+        return dh, dw
+
+
+class _OutProjFn(torch.autograd.Function):
+    """y = out_proj(mix) with mix the (batch, e, seqlen) view of (e, batch, seqlen) storage, read as the transposed
+    (e, batch*seqlen) matrix; weight gradient per utterance + sum."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, mix, weight, bias):
+        batch, e, seqlen = mix.shape
+        ctx.save_for_backward(mix, weight)
+        ctx.has_bias = bias is not None
+        w = weight.to(mix.dtype)
+        y = torch.mm(mix.permute(1, 0, 2).reshape(e, batch * seqlen).t(), w.t())
+        if bias is not None:
+            y = y + bias.to(y.dtype)
+        return y.view(batch, seqlen, -1)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        mix, weight = ctx.saved_tensors
+        batch, e, seqlen = mix.shape
+        dy = dy.to(mix.dtype)
+        dmix = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dmix = (weight.t().to(dy.dtype) @ dy.reshape(batch * seqlen, -1).t()).view(e, batch, seqlen).transpose(0, 1)
+        if ctx.needs_input_grad[1]:
+            dw = torch.bmm(dy.transpose(1, 2), mix.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(batch * seqlen, -1).sum(0)
+        return dmix, dw, db
+
+
 def _init_dt_proj(dt_proj: nn.Linear, d_inner, dt_rank, dt_init, dt_scale, dt_min, dt_max, dt_init_floor, fk):
     """reference bimamba.py:101-120."""
     std = dt_rank ** -0.5 * dt_scale
@@ -107,8 +166,10 @@ class Mamba(nn.Module):
                                       "training/encoder path and has no HIP kernel yet")
         batch, seqlen, _ = hidden_states.shape
         # in_proj with the (b l d) -> (b d l) transpose folded in (reference :192-198)
-        xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen)
-        xz = xz.transpose(0, 1)
+        if hidden_states.is_cuda:
+            xz = _InProjFn.apply(hidden_states, self.in_proj.weight)
+        else:
+            xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen).transpose(0, 1)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         # xz stays the (b, 2e, l) VIEW of the GEMM's (2e, b, l) output: time-contiguous, which is all the kernels need
@@ -130,12 +191,8 @@ class Mamba(nn.Module):
         mix = 0.5 * out + 0.5 * out_b if self.if_devide_out else out + out_b      # reference :250-253
         # out / out_b are (b, e, l) views of (e, b, l) storage (selective_scan_interface._ebt), and so is mix: out_proj
         # reads it as the transposed (e, b*l) matrix instead of copying it to (b, l, e)
-        mix_t = mix.permute(1, 0, 2)
-        if mix_t.is_contiguous():
-            w = self.out_proj.weight.to(mix.dtype) if torch.is_autocast_enabled("cuda") else self.out_proj.weight
-            y = torch.mm(mix_t.reshape(self.d_inner, batch * seqlen).t(), w.t()).view(batch, seqlen, -1)
-            if self.out_proj.bias is not None:
-                y = y + self.out_proj.bias.to(y.dtype)
+        if mix.is_cuda and mix.permute(1, 0, 2).is_contiguous():
+            y = _OutProjFn.apply(mix, self.out_proj.weight, self.out_proj.bias)
         else:
             y = F.linear(mix.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
         if self.init_layer_scale is not None:

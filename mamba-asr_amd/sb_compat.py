@@ -40,6 +40,49 @@ class LayerNorm(nn.Module):
         return self.norm(x)
 
 
+class _LinearRowsFn(torch.autograd.Function):
+    """y = x W^T + b with the WEIGHT gradient formed per utterance and summed: as one GEMM with K = batch*time and a
+    256 x 1024 output the library runs 64 workgroups on 256 CUs (no split-K: 165 us, 100 TFLOP/s at 32 x 1000 rows);
+    a batched product over the batch axis fills the chip, then one small reduction."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy, weight.to(dy.dtype))
+        if ctx.needs_input_grad[1]:
+            if x.dim() == 3 and x.shape[0] > 1:
+                dw = torch.bmm(dy.transpose(1, 2), x.to(dy.dtype)).sum(0)
+            else:
+                dw = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]).to(dy.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, dy.shape[-1]).sum(0)
+        return dx, dw, db
+
+
+def linear_rows(x, weight, bias=None):
+    """F.linear whose weight gradient is a batched (per-utterance) product on the GPU; plain F.linear elsewhere."""
+    if x.is_cuda and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
+        return _LinearRowsFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class RowsLinear(nn.Linear):
+    """nn.Linear (same parameters and state_dict keys) on linear_rows."""
+
+    def forward(self, x):
+        return linear_rows(x, self.weight, self.bias)
+
+
 class Linear(nn.Module):
     """speechbrain.nnet.linear.Linear: nn.Linear under ``.w``."""
 
@@ -78,8 +121,8 @@ class PositionalwiseFeedForward(nn.Module):
         super().__init__()
         if input_size is None:
             input_size = input_shape[-1]
-        self.ffn = nn.Sequential(nn.Linear(input_size, d_ffn), activation(), nn.Dropout(dropout),
-                                 nn.Linear(d_ffn, input_size))
+        self.ffn = nn.Sequential(RowsLinear(input_size, d_ffn), activation(), nn.Dropout(dropout),
+                                 RowsLinear(d_ffn, input_size))
 
     def forward(self, x):
         return self.ffn(x)
