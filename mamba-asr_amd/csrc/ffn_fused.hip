@@ -18,6 +18,8 @@
 #include "cm_common.h"
 #include <type_traits>
 
+extern "C" int cm_debug_get();
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -42,7 +44,23 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-template <bool ADD>
+// GELU of two accumulators at once: the polynomial and the products are v_pk_*_f32 (two results per issue slot)
+__device__ __forceinline__ uint32_t gelu_pack2(float a, float b) {
+    const f32x2 x = {a, b};
+    f32x2 x2 = x * x;
+    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    f32x2 q = __builtin_elementwise_fma(x2, f32x2{7.03033577e-04f * CM_LOG2E, 7.03033577e-04f * CM_LOG2E},
+                                        f32x2{-7.40112920e-02f * CM_LOG2E, -7.40112920e-02f * CM_LOG2E});
+    q = __builtin_elementwise_fma(x2, q, f32x2{-1.59501577f * CM_LOG2E, -1.59501577f * CM_LOG2E});
+    const f32x2 e = x * q;
+    const f32x2 d = f32x2{cm_exp2(e.x), cm_exp2(e.y)} + f32x2{1.0f, 1.0f};
+    const f32x2 r = x * f32x2{cm_rcp(d.x), cm_rcp(d.y)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
+// VAR (cm_debug_set, timing only): 1 = packed GELU, 2 = no GELU, 3 = no weight stream after the first fill,
+// 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4
+template <bool ADD, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
@@ -72,7 +90,8 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(W2), 0, F * D * 2, 0x00020000);
     const int vl = lane * 16;
     const int kt2 = F / 32;                                       // tiles per 16-row band of W2
-    auto wload = [&](int c, int s, bf16x8(&dst)[4]) {
+    auto wload = [&](int c, int s, bf16x8(&dst)[4], bool first = false) {
+        if constexpr (VAR == 3 || VAR == 5) { if (!first) return; }
         if (s < 8) {                                              // W1 band (c*CH + wave*64)/16 + mb, tile s
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     };
     bf16x8 wq[PF][4];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) wload(0, s, wq[s]);
+    for (int s = 0; s < PF; ++s) wload(0, s, wq[s], true);
 
     for (int i = tid; i < p.hidden; i += NT) b1s[i] = p.b1[i];
 
@@ -172,9 +191,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
         read_frags(xfrag, 0, bfa);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+            bf16x8(&cur)[4] = (s & 1) && !(VAR == 4 || VAR == 5) ? bfb : bfa;
             bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
-            if (s + 1 < 8) read_frags(xfrag, s + 1, nxt);
+            if (s + 1 < 8 && !(VAR == 4 || VAR == 5)) read_frags(xfrag, s + 1, nxt);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -191,8 +210,16 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 uint2 pk;
+                if constexpr (VAR == 1) {
+                    pk.x = gelu_pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
+                    pk.y = gelu_pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
+                } else if constexpr (VAR == 2 || VAR == 5) {
+                    pk.x = pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
+                    pk.y = pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
+                } else {
                 pk.x = pack2(cm_gelu_bf16(acc1[mb][nb][0] + bv.x), cm_gelu_bf16(acc1[mb][nb][1] + bv.y));
                 pk.y = pack2(cm_gelu_bf16(acc1[mb][nb][2] + bv.z), cm_gelu_bf16(acc1[mb][nb][3] + bv.w));
+                }
                 *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
             }
         }
@@ -212,9 +239,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
         read_frags(hfrag, 0, bfa);
 #pragma unroll
         for (int s = 8; s < 16; ++s) {
-            bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+            bf16x8(&cur)[4] = (s & 1) && !(VAR == 4 || VAR == 5) ? bfb : bfa;
             bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
-            if (s + 1 < 16) read_frags(hfrag, s + 1 - 8, nxt);
+            if (s + 1 < 16 && !(VAR == 4 || VAR == 5)) read_frags(hfrag, s + 1 - 8, nxt);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -343,12 +370,12 @@ __global__ void ffn_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__rest
     *reinterpret_cast<uint4 *>(out + piece * 8) = *reinterpret_cast<const uint4 *>(w + (int64_t)r * K + k);
 }
 
-template <bool ADD>
-int launch(const cm_ffn_args &a) {
+template <bool ADD, int VAR>
+int launch_var(const cm_ffn_args &a) {
     const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)4 * TOK * sizeof(float) + (size_t)a.hidden * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<ADD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<ADD, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -357,8 +384,20 @@ int launch(const cm_ffn_args &a) {
         attr_done = true;
     }
     dim3 grid((a.rows + TOK - 1) / TOK);
-    hipLaunchKernelGGL((ffn_fused_kernel<ADD>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    hipLaunchKernelGGL((ffn_fused_kernel<ADD, VAR>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_ffn_fused");
+}
+
+template <bool ADD>
+int launch(const cm_ffn_args &a) {
+    switch (cm_debug_get()) {
+        case 1: return launch_var<ADD, 1>(a);
+        case 2: return launch_var<ADD, 2>(a);
+        case 3: return launch_var<ADD, 3>(a);
+        case 4: return launch_var<ADD, 4>(a);
+        case 5: return launch_var<ADD, 5>(a);
+        default: return launch_var<ADD, 0>(a);
+    }
 }
 
 }  // namespace

@@ -28,6 +28,15 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// softplus (beta 1, threshold 20; reference selective_scan_interface.py:112) as max(x, 0) + log1p(e^-|x|): two
+// transcendentals + four plain slots and no selects.  Beyond x = 20 the log term is exactly 0 in fp32 (the reference's
+// threshold branch); for very negative x the absolute error is that of 1 + e^x (6e-8).
+__device__ __forceinline__ float softplus_rows(float x) {
+    const float e = cm_exp2(-CM_LOG2E * fabsf(x));
+    return fmaf(CM_LN2, cm_log2(1.0f + e), fmaxf(x, 0.f));
+}
 
 constexpr int TB = 16;        // steps per block (= MFMA M)
 constexpr int NBUF = 3;       // staged input tiles
@@ -113,7 +122,10 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     const bool x_thread = tid < TB * XCPR;
     int x_off = x_thread ? ((tb0 + tid / XCPR) * x_ts + (tid % XCPR) * VEC) * S : 0x7fffffff;
     const int x_step = x_thread ? DIR * TB * x_ts * S : 0;
-    const int x_lds = L::kX + ((tid / XCPR) * XS + (tid % XCPR) * VEC) * 4;
+    // bf16 I/O: the dt columns (chunks 0, 1 of a row) stay RAW bf16 in the first 32 bytes of the staged row -- they are
+    // the A operand of one bf16 MFMA; B and C (chunks 2..5) are widened to fp32 at floats 16..47 for the recurrence
+    const bool x_raw = S == 2 && tid % XCPR < 2;
+    const int x_lds = L::kX + (tid / XCPR) * XS * 4 + (x_raw ? (tid % XCPR) * 16 : (tid % XCPR) * VEC * 4);
     u32x4 ruz[NV], rx;
     auto issue = [&]() {                                          // next block in processing order
 #pragma unroll
@@ -128,12 +140,16 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     auto commit = [&](const int buf_tile, const int buf_x) {      // byte offsets of the destination tiles
 #pragma unroll
         for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4 *>(lds + uz_lds[i] + buf_tile) = ruz[i];
-        if (x_thread) unpack_store(reinterpret_cast<float *>(lds + x_lds + buf_x), uint4{rx[0], rx[1], rx[2], rx[3]}, IO{});
+        if (x_thread) {
+            if (x_raw) *reinterpret_cast<u32x4 *>(lds + x_lds + buf_x) = rx;
+            else unpack_store(reinterpret_cast<float *>(lds + x_lds + buf_x), uint4{rx[0], rx[1], rx[2], rx[3]}, IO{});
+        }
     };
 
     // ---- per-lane constants: 4 states of one channel
     f32x2 Ap01, Ap23, h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
     float Wdt[4];
+    bf16x8 Wdt8;                                                  // bf16 I/O: W_dt[c][8g .. 8g+7] for g < 2, zero above (K = 32 padded)
     {
         const float4 a4 = *reinterpret_cast<const float4 *>(d.A + (int64_t)cc * 16 + 4 * g);
         Ap01 = f32x2{a4.x * CM_LOG2E, a4.y * CM_LOG2E};
@@ -141,6 +157,15 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         // B operand of the delta MFMAs: lane (n = channel, k = lane group) holds W_dt[c][4k + q], q = 0..3
         const float4 w4 = *reinterpret_cast<const float4 *>(d.dt_weight + (int64_t)cc * 16 + 4 * g);
         Wdt[0] = w4.x; Wdt[1] = w4.y; Wdt[2] = w4.z; Wdt[3] = w4.w;
+        if constexpr (S == 2) {
+            // The reference runs this product as a bf16 GEMM under autocast (selective_scan_interface.py:187: weight and
+            // x_dbl both cast to bf16, fp32 accumulate); here too, except that delta stays fp32 afterwards.
+            const float *wr = d.dt_weight + (int64_t)cc * 16 + 8 * (g & 1);
+            const float4 lo = *reinterpret_cast<const float4 *>(wr), hi = *reinterpret_cast<const float4 *>(wr + 4);
+            const float sc = g < 2 ? 1.f : 0.f;
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            Wdt8 = __builtin_convertvector(f32x8{lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc}, bf16x8);
+        }
     }
     const float bias = d.delta_bias ? d.delta_bias[cc] : 0.f;
     const float Dv = d.D ? d.D[cc] : 0.f;
@@ -159,13 +184,21 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     auto produce_impl = [&](const int buf_tile, const int buf_x, const int tb, auto ragged_tag) {
         constexpr bool ragged = decltype(ragged_tag)::value;      // only the sequence's last block has padded steps
         const float *xt = reinterpret_cast<const float *>(lds + L::kX + buf_x);
-        // A operand: lane (m = step = lane%16, k = lane/16) holds dt[step][4k + q]
-        const f32x4 dtf = *reinterpret_cast<const f32x4 *>(xt + c16 * XS + 4 * g);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[0], Wdt[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[1], Wdt[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[2], Wdt[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[3], Wdt[3], acc, 0, 0, 0);
+        if constexpr (S == 2) {
+            // ONE v_mfma_f32_16x16x32_bf16 (4 passes) instead of four fp32 MFMAs (8 passes each).  A operand: lane
+            // (m = step = lane%16, k block = lane/16) holds dt[step][8k .. 8k+7]; the blocks k = 2, 3 re-read blocks
+            // 0, 1 (finite data) against zero weights.
+            const bf16x8 dt8 = *reinterpret_cast<const bf16x8 *>(xt + c16 * XS + 4 * (g & 1));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt8, Wdt8, acc, 0, 0, 0);
+        } else {
+            // A operand: lane (m = step = lane%16, k = lane/16) holds dt[step][4k + q]
+            const f32x4 dtf = *reinterpret_cast<const f32x4 *>(xt + c16 * XS + 4 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[0], Wdt[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[1], Wdt[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[2], Wdt[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dtf[3], Wdt[3], acc, 0, 0, 0);
+        }
         // acc[i] = delta_raw[step 4g+i][channel c16]
         const IO *ut = reinterpret_cast<const IO *>(lds + L::kU + buf_tile) + 16 * w + c16 + 4 * g * 64;
         const IO *zt = reinterpret_cast<const IO *>(lds + L::kZ + buf_tile) + 16 * w + c16 + 4 * g * 64;
@@ -173,7 +206,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float dv = acc[i] + bias;
-            if (softplus && ABL != 3) dv = cm_softplus(dv);
+            if (softplus && ABL != 3) dv = softplus_rows(dv);
             if (ragged) dv = tb + 4 * g + i < T ? dv : 0.f;       // padded steps: a = 1, b = 0 (state passes through)
             const float uv = ld_io(ut + i * 64);
             uq[i] = uv;

@@ -259,7 +259,10 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
         xd = xcat[:, :, 48 * i:48 * (i + 1)].float()                     # what the kernel sees
         Wdt = torch.randn(e, rank, generator=gen) * 0.3
         D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
-        delta = torch.einsum("er,blr->bel", Wdt.double(), xd[:, :, :rank].double())        # (b, e, l), pre-bias
+        # bf16 I/O: the kernel runs the dt_proj product as a bf16 MFMA (weight rounded to bf16, fp32 accumulate), which is
+        # what the reference does under autocast (selective_scan_interface.py:187); the oracle sees the same rounded weight
+        Wq = Wdt.to(dtype).float()
+        delta = torch.einsum("er,blr->bel", Wq.double(), xd[:, :, :rank].double())         # (b, e, l), pre-bias
         Bm, Cm = xd[:, :, 16:32].transpose(1, 2), xd[:, :, 32:48].transpose(1, 2)          # (b, 16, l)
         f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
         tr = lambda t: t.float().transpose(1, 2)
@@ -280,7 +283,7 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     (got,) = ops.scan_cl_fwd([dict(u=dirs[0]["u"], A=dirs[0]["A"], dt_weight=dirs[0]["dt_weight"], xdbl=dirs[0]["xdbl"])],
                              delta_softplus=False)
     xd = xcat[:, :, :48].float()
-    Wp = dirs[0]["dt_weight"].cpu()
+    Wp = dirs[0]["dt_weight"].cpu().to(dtype).float()
     delta = torch.einsum("er,blr->bel", Wp.double(), xd[:, :, :16].double())
     ref = O.selective_scan(dirs[0]["u"].cpu().float().transpose(1, 2), delta, dirs[0]["A"].cpu(), xd[:, :, 16:32].transpose(1, 2),
                            xd[:, :, 32:48].transpose(1, 2), None, None, None, False, work_dtype=torch.float64)

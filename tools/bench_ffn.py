@@ -33,6 +33,21 @@ def timeit(fn, iters=20, warm=3, reps=5):
 
 def main():
     dev = "cuda"
+    variants = [int(v) for v in os.environ.get("VAR", "").split(",") if v]      # timing-only kernel variants (ffn_fused.hip)
+    if variants:
+        from mamba_asr_amd import _native
+        rows, hidden = 64000, 1024
+        x = torch.randn(rows, 256, device=dev)
+        w1p = ops.PackedWeight((torch.randn(hidden, 256, device=dev) / 16).bfloat16())
+        w2p = ops.PackedWeight((torch.randn(256, hidden, device=dev) / 32).bfloat16())
+        b1, b2 = torch.randn(hidden, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+        ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
+        for v in [0] + variants:
+            _native.lib().cm_debug_set(v)
+            t = timeit(lambda: ops.ffn_fused(x, ln, w1p, b1, w2p, b2, alpha=0.5, norm2=ln))
+            print(f"rows {rows}: variant {v}: {t:7.1f} us", flush=True)
+        _native.lib().cm_debug_set(0)
+        return
     for rows in (10667, 16000, 32000, 64000):
         hidden = 1024
         x = torch.randn(rows, 256, device=dev)
