@@ -288,12 +288,16 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
                     const int c = 4 * (l15 + 16 * i);
                     const float4 gm = *reinterpret_cast<const float4 *>(p.ln_g + c);
                     const float4 bt = *reinterpret_cast<const float4 *>(p.ln_b + c);
-                    // outputs rounded to bf16 take the 7-slot GELU (cm_gelu_bf16: 2.6e-5 from the erf form); fp32 outputs the erf form
-                    auto act = [](float x) { if constexpr (sizeof(IO) == 2) return cm_gelu_bf16(x); else return gelu_erf(x); };
-                    float o[4] = {act(fmaf(v[i].x * rstd, gm.x, bt.x)), act(fmaf(v[i].y * rstd, gm.y, bt.y)),
-                                  act(fmaf(v[i].z * rstd, gm.z, bt.z)), act(fmaf(v[i].w * rstd, gm.w, bt.w))};
+                    // outputs rounded to bf16 take the 7-slot GELU (cm_gelu_bf16: 2.6e-5 from the erf form), two at a time; fp32 outputs the erf form
+                    const float y0 = fmaf(v[i].x * rstd, gm.x, bt.x), y1 = fmaf(v[i].y * rstd, gm.y, bt.y);
+                    const float y2 = fmaf(v[i].z * rstd, gm.z, bt.z), y3 = fmaf(v[i].w * rstd, gm.w, bt.w);
+                    if constexpr (sizeof(IO) == 2) {
+                        *reinterpret_cast<uint2 *>(out + (int64_t)t * D + c) = make_uint2(cm_gelu_bf16_pack2(y0, y1), cm_gelu_bf16_pack2(y2, y3));
+                    } else {
+                        const float o[4] = {gelu_erf(y0), gelu_erf(y1), gelu_erf(y2), gelu_erf(y3)};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) cm_elem<IO>::store(out + (int64_t)t * D + c + j, o[j]);
+                        for (int j = 0; j < 4; ++j) cm_elem<IO>::store(out + (int64_t)t * D + c + j, o[j]);
+                    }
                 }
             }
         }

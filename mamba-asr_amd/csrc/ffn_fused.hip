@@ -44,22 +44,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-// GELU of two accumulators at once: the polynomial and the products are v_pk_*_f32 (two results per issue slot)
-__device__ __forceinline__ uint32_t gelu_pack2(float a, float b) {
-    const f32x2 x = {a, b};
-    f32x2 x2 = x * x;
-    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
-    f32x2 q = __builtin_elementwise_fma(x2, f32x2{7.03033577e-04f * CM_LOG2E, 7.03033577e-04f * CM_LOG2E},
-                                        f32x2{-7.40112920e-02f * CM_LOG2E, -7.40112920e-02f * CM_LOG2E});
-    q = __builtin_elementwise_fma(x2, q, f32x2{-1.59501577f * CM_LOG2E, -1.59501577f * CM_LOG2E});
-    const f32x2 e = x * q;
-    const f32x2 d = f32x2{cm_exp2(e.x), cm_exp2(e.y)} + f32x2{1.0f, 1.0f};
-    const f32x2 r = x * f32x2{cm_rcp(d.x), cm_rcp(d.y)};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-}
-
-// VAR (cm_debug_set, timing only): 1 = packed GELU, 2 = no GELU, 3 = no weight stream after the first fill,
-// 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4
+// VAR (cm_debug_set, timing only): 1 = scalar GELU (cm_gelu_bf16 per element; 108-110 us vs 99-100 us packed at 64k rows), 2 = no GELU, 3 = no weight stream after the first fill,
+// 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4, 6 / 7 = workgroups of the second occupancy slot
+// (ids 256..511 of each 512) start 3.4 / 10 us late so that a CU's two workgroups are in different phases
 template <bool ADD, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -69,6 +56,10 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     float *b1s = red + 4 * TOK;                                   // [hidden] first bias (a global load inside the slab
                                                                   // loop would wait on vmcnt and drain the weight ring)
     const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (VAR == 6 || VAR == 7) {
+        if ((blockIdx.x >> 8) & 1)
+            for (int i = 0; i < (VAR == 6 ? 1 : 3); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 4*TH-1: owns tokens 16 wv .. +15 in the LayerNorm phases
     const int wave = wv & 3;                                      // feature quarter (uniform: feeds the buffer loads' scalar offset)
     const int th = wv >> 2;                                       // token half in the GEMMs / epilogue
@@ -211,14 +202,14 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             for (int nb = 0; nb < 4; ++nb) {
                 uint2 pk;
                 if constexpr (VAR == 1) {
-                    pk.x = gelu_pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
-                    pk.y = gelu_pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
+                    pk.x = pack2(cm_gelu_bf16(acc1[mb][nb][0] + bv.x), cm_gelu_bf16(acc1[mb][nb][1] + bv.y));
+                    pk.y = pack2(cm_gelu_bf16(acc1[mb][nb][2] + bv.z), cm_gelu_bf16(acc1[mb][nb][3] + bv.w));
                 } else if constexpr (VAR == 2 || VAR == 5) {
                     pk.x = pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
                     pk.y = pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
                 } else {
-                pk.x = pack2(cm_gelu_bf16(acc1[mb][nb][0] + bv.x), cm_gelu_bf16(acc1[mb][nb][1] + bv.y));
-                pk.y = pack2(cm_gelu_bf16(acc1[mb][nb][2] + bv.z), cm_gelu_bf16(acc1[mb][nb][3] + bv.w));
+                    pk.x = cm_gelu_bf16_pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
+                    pk.y = cm_gelu_bf16_pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
                 }
                 *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
             }
@@ -396,6 +387,8 @@ int launch(const cm_ffn_args &a) {
         case 3: return launch_var<ADD, 3>(a);
         case 4: return launch_var<ADD, 4>(a);
         case 5: return launch_var<ADD, 5>(a);
+        case 6: return launch_var<ADD, 6>(a);
+        case 7: return launch_var<ADD, 7>(a);
         default: return launch_var<ADD, 0>(a);
     }
 }

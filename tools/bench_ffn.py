@@ -42,7 +42,9 @@ def main():
         w2p = ops.PackedWeight((torch.randn(256, hidden, device=dev) / 32).bfloat16())
         b1, b2 = torch.randn(hidden, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
         ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
-        for v in [0] + variants:
+        for _ in range(300):                                   # clocks settle: the first case measured was 5-7 % slow without this
+            ops.ffn_fused(x, ln, w1p, b1, w2p, b2, alpha=0.5, norm2=ln)
+        for v in [0] + variants + [0]:
             _native.lib().cm_debug_set(v)
             t = timeit(lambda: ops.ffn_fused(x, ln, w1p, b1, w2p, b2, alpha=0.5, norm2=ln))
             print(f"rows {rows}: variant {v}: {t:7.1f} us", flush=True)
