@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 2
+#define CM_ABI_VERSION 3
 
 /* error codes */
 #define CM_OK            0
@@ -403,6 +403,36 @@ typedef struct cm_dwconv_cl_args {
 int64_t cm_dwconv_cl_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);
 int cm_dwconv_cl_fwd(const cm_dwconv_cl_args *args);
 int cm_dwconv_cl_bwd(const cm_dwconv_cl_args *args);
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm over the last axis with saved statistics, forward and backward (training path).  Replaces torch's
+ * LayerNorm behind the reference's normalisations: modules/Conmamba.py:262, :287 (ConvolutionModule), :597-620
+ * (feed-forward pre-norms, norm1, norm2), :687 (final norm) -- under autocast torch runs them in fp32 whatever the
+ * input type, so x may be bf16 while y is fp32.
+ *   fwd: y = (x - mean) * rstd * gamma + beta over rows of `dim` (multiple of 4, <= 1024), contiguous; mean / rstd
+ *        (rows) fp32 are written when given (both or neither).
+ *   bwd: dx (x_dtype, may be NULL) and dgamma / dbeta (dim, OVERWRITTEN) from dy (y_dtype), x, mean, rstd, gamma;
+ *        workspace: cm_layernorm_bwd_workspace_floats(rows, dim) fp32, caller-owned; fixed summation order.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_layernorm_args {
+    int64_t rows;
+    int32_t dim;
+    int32_t x_dtype, y_dtype;    /* CM_F32 or CM_BF16 */
+    float   eps;
+    const void  *x;
+    const float *gamma, *beta;
+    void  *y;                    /* forward  */
+    float *mean, *rstd;          /* forward: written (optional); backward: read */
+    const void *dy;              /* backward */
+    void  *dx;
+    float *dgamma, *dbeta;
+    float *workspace;
+    void  *stream;
+} cm_layernorm_args;
+
+int64_t cm_layernorm_bwd_workspace_floats(int64_t rows, int32_t dim);
+int cm_layernorm_fwd(const cm_layernorm_args *args);
+int cm_layernorm_bwd(const cm_layernorm_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * Mixer -> convolution-module seam in one kernel (bf16 GEMM operands, d_model 256):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libconmamba_hip.so")
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -125,6 +125,14 @@ class DwconvClArgs(C.Structure):
     ]
 
 
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("rows", i64), ("dim", i32), ("x_dtype", i32), ("y_dtype", i32), ("eps", C.c_float),
+        ("x", vp), ("gamma", fp), ("beta", fp), ("y", vp), ("mean", fp), ("rstd", fp),
+        ("dy", vp), ("dx", vp), ("dgamma", fp), ("dbeta", fp), ("workspace", fp), ("stream", vp),
+    ]
+
+
 class LnPwGluArgs(C.Structure):
     _fields_ = [
         ("rows", i32), ("dim", i32), ("x", fp), ("y", vp), ("ln_g", fp), ("ln_b", fp), ("w", vp), ("bias", fp),
@@ -228,6 +236,9 @@ SYMBOLS = [
     ("cm_ln_pw_glu", C.c_int, [C.POINTER(LnPwGluArgs)]),
     ("cm_causal_conv1d_update", C.c_int, [C.POINTER(ConvUpdateArgs)]),
     ("cm_selective_state_update", C.c_int, [C.POINTER(StateUpdateArgs)]),
+    ("cm_layernorm_bwd_workspace_floats", C.c_int64, [i64, i32]),
+    ("cm_layernorm_fwd", C.c_int, [C.POINTER(LayerNormArgs)]),
+    ("cm_layernorm_bwd", C.c_int, [C.POINTER(LayerNormArgs)]),
     ("cm_dwconv_cl_workspace_floats", C.c_int64, [i32, i32, i32]),
     ("cm_dwconv_cl_fwd", C.c_int, [C.POINTER(DwconvClArgs)]),
     ("cm_dwconv_cl_bwd", C.c_int, [C.POINTER(DwconvClArgs)]),

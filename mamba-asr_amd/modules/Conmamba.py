@@ -19,7 +19,7 @@ import torch.nn.functional as F
 import os
 
 from .. import ops
-from ..sb_compat import LayerNorm, PositionalwiseFeedForward, RowsLinear, Swish, linear_rows
+from ..sb_compat import LayerNorm, PositionalwiseFeedForward, RowsLayerNorm, RowsLinear, Swish, linear_rows
 from .mamba.bimamba import Mamba as BiMamba
 from .mamba.bimamba import UniMamba as Mamba
 
@@ -42,12 +42,12 @@ class ConvolutionModule(nn.Module):
         self.kernel_size, self.causal, self.dilation = kernel_size, causal, dilation
         span = (kernel_size - 1) * 2 ** (dilation - 1)
         self.padding = span if causal else span // 2
-        self.layer_norm = nn.LayerNorm(input_size)
+        self.layer_norm = RowsLayerNorm(input_size)
         self.bottleneck = nn.Sequential(nn.Conv1d(input_size, 2 * input_size, kernel_size=1, stride=1, bias=bias),
                                         nn.GLU(dim=1))
         self.conv = nn.Conv1d(input_size, input_size, kernel_size=kernel_size, stride=1, padding=self.padding,
                               dilation=dilation, groups=input_size, bias=bias)
-        self.after_conv = nn.Sequential(nn.LayerNorm(input_size), activation(),
+        self.after_conv = nn.Sequential(RowsLayerNorm(input_size), activation(),
                                         RowsLinear(input_size, input_size, bias=bias), nn.Dropout(dropout))
 
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
@@ -95,7 +95,7 @@ class ConmambaEncoderLayer(nn.Module):
         self.convolution_module = ConvolutionModule(d_model, kernel_size, bias, activation, dropout, causal=causal)
 
         def ffn():
-            return nn.Sequential(nn.LayerNorm(d_model),
+            return nn.Sequential(RowsLayerNorm(d_model),
                                  PositionalwiseFeedForward(d_ffn=d_ffn, input_size=d_model, dropout=dropout,
                                                            activation=activation),
                                  nn.Dropout(dropout))

@@ -569,6 +569,70 @@ class DepthwiseConvClFn(torch.autograd.Function):
         return dx, dw.reshape(weight.shape).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
 
 
+def _layernorm_args(x2, weight, eps, y_dtype):
+    a = N.LayerNormArgs()
+    a.rows, a.dim, a.x_dtype, a.y_dtype, a.eps = x2.shape[0], x2.shape[1], _DT[x2.dtype], _DT[y_dtype], float(eps)
+    a.x, a.gamma, a.stream = _ptr(x2), _ptr(weight), _stream()
+    return a
+
+
+def layernorm_fwd(x, weight, bias, eps, out_dtype=None):
+    """LayerNorm over the last axis (cm_layernorm_fwd) -> (y, mean, rstd); x fp32 or bf16, contiguous rows; y in
+    `out_dtype` (default fp32: what torch's autocast gives, reference modules/Conmamba.py:597-620)."""
+    _dev_check(x, weight, bias)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"layernorm_fwd: unsupported dtype {x.dtype}")
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    out_dtype = out_dtype or torch.float32
+    w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    y = torch.empty(x2.shape, dtype=out_dtype, device=x.device)
+    stats = torch.empty((2, x2.shape[0]), dtype=torch.float32, device=x.device)
+    a = _layernorm_args(x2, w, eps, out_dtype)
+    a.beta, a.y, a.mean, a.rstd = _ptr(b), _ptr(y), _ptr(stats[0]), _ptr(stats[1])
+    _launch("cm_layernorm_fwd", N.lib().cm_layernorm_fwd, a, units=x2.shape[0])
+    return y.view(x.shape), x2, stats
+
+
+def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True):
+    """-> (dx (x2's dtype and shape) or None, dgamma, dbeta (dim) fp32) of layernorm_fwd (cm_layernorm_bwd, deterministic)."""
+    _dev_check(dy, x2, stats, weight)
+    dy2 = dy.reshape(x2.shape)
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    w = weight.detach().float().contiguous()
+    dx = torch.empty_like(x2) if need_dx else None
+    dgb = torch.empty((2, x2.shape[1]), dtype=torch.float32, device=x2.device)
+    ws = torch.empty((N.lib().cm_layernorm_bwd_workspace_floats(x2.shape[0], x2.shape[1]),), dtype=torch.float32, device=x2.device)
+    a = _layernorm_args(x2, w, eps, dy2.dtype)
+    a.mean, a.rstd, a.dy, a.dx = _ptr(stats[0]), _ptr(stats[1]), _ptr(dy2), _ptr(dx)
+    a.dgamma, a.dbeta, a.workspace = _ptr(dgb[0]), _ptr(dgb[1]), _ptr(ws)
+    _launch("cm_layernorm_bwd", N.lib().cm_layernorm_bwd, a, units=x2.shape[0])
+    return dx, dgb[0], dgb[1]
+
+
+class LayerNormFn(torch.autograd.Function):
+    """autograd node over cm_layernorm_fwd / _bwd.  Output fp32 under autocast or for fp32 input (torch's rule), else the
+    input dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        out_dtype = torch.float32 if (x.dtype == torch.float32 or torch.is_autocast_enabled("cuda")) else x.dtype
+        y, x2, stats = layernorm_fwd(x, weight, bias, eps, out_dtype)
+        ctx.save_for_backward(x2, stats, weight)
+        ctx.eps, ctx.shape = eps, x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats, weight = ctx.saved_tensors
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dx, dg, db = layernorm_bwd(dy, x2, stats, weight, ctx.eps, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.shape) if dx is not None else None), dg.to(weight.dtype), db.to(weight.dtype), None
+
+
 def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
     """Mixer -> convolution-module seam (cm_ln_pw_glu): x_out = x + alpha*y; g = GLU(LayerNorm(x_out) @ W^T + bias).
     x (rows, 256) fp32 contiguous; y (rows, 256) bf16 or None; norm = (weight, bias, eps); w: PackedWeight of the

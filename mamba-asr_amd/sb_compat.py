@@ -26,6 +26,23 @@ class Swish(nn.Module):
         return x * torch.sigmoid(self.beta * x)
 
 
+# LayerNorm of row tensors on cm_layernorm_fwd / _bwd (csrc/layernorm_train.hip); CM_NATIVE_LN=0 keeps torch's kernels
+USE_NATIVE_LN = os.environ.get("CM_NATIVE_LN", "1") == "1"
+
+
+class RowsLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters and state_dict keys) whose GPU forward/backward over a single normalised axis run
+    on the native kernels; other shapes (the CNN front end's (freq, channel) norm) and CPU tensors take torch's path."""
+
+    def forward(self, x):
+        if (USE_NATIVE_LN and x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
+                and self.normalized_shape[0] % 4 == 0 and self.normalized_shape[0] <= 1024
+                and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
+            from . import ops
+            return ops.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 class LayerNorm(nn.Module):
     """speechbrain.nnet.normalization.LayerNorm: nn.LayerNorm under ``.norm`` (keys norm.weight/bias)."""
 
@@ -34,7 +51,7 @@ class LayerNorm(nn.Module):
         if input_shape is not None:
             input_size = input_shape[2:]
         self.eps = eps
-        self.norm = nn.LayerNorm(input_size, eps=eps, elementwise_affine=elementwise_affine)
+        self.norm = RowsLayerNorm(input_size, eps=eps, elementwise_affine=elementwise_affine)
 
     def forward(self, x):
         return self.norm(x)

@@ -400,6 +400,42 @@ def test_dwconv_channels_last_forward_backward(ops, shape, k, causal, dtype):
     assert torch.equal(dw2.reshape(wg.grad.shape), wg.grad.float()) and torch.equal(db2, bg.grad.float())
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 256), (1, 1, 144), (2, 1000, 256), (5, 333, 144), (2, 129, 512), (1, 70, 640), (3, 50, 1024),
+                                   (4, 4099, 256), (2, 17, 8)])
+@pytest.mark.parametrize("mode", ["f32", "bf16_autocast", "bf16_plain"])
+def test_layernorm_forward_backward(ops, shape, mode):
+    """cm_layernorm_fwd / _bwd through the autograd node the module API uses vs torch's LayerNorm + autograd in float64:
+    both lane mappings (16 and 64 lanes per row), dims that leave lanes idle (144, 8, 640), row counts that are not a
+    multiple of the rows per wave, bf16 input with fp32 output (autocast) and bf16 in/out; the gamma / beta gradients are
+    bit-identical between two runs (fixed-order reduction)."""
+    b, l, d = shape
+    gen = torch.Generator().manual_seed(l * 7 + d)
+    dt_in = torch.float32 if mode == "f32" else torch.bfloat16
+    x = (torch.randn(b, l, d, generator=gen) * 2.0 + 0.5).to(dt_in)
+    w, bias = torch.randn(d, generator=gen) * 0.5 + 1.0, torch.randn(d, generator=gen) * 0.2
+    dt_out = torch.bfloat16 if mode == "bf16_plain" else torch.float32
+    dy = torch.randn(b, l, d, generator=gen).to(dt_out)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    ref.backward(dy.double())
+    xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "bf16_autocast"):
+        got = ops.LayerNormFn.apply(xg, wg, bg, 1e-5)
+    assert got.dtype == dt_out and got.shape == x.shape
+    got.backward(dy.to(DEV))
+    ft = (1e-5, 1e-5) if dt_out == torch.float32 else (1.6e-2, 1e-2)
+    gt = (1e-4, 1e-4) if mode == "f32" else (1.6e-2, 1e-2)          # dx is rounded to the input dtype
+    close(got.float(), ref, *ft)
+    close(xg.grad.float(), xr.grad, *gt)
+    scale = lambda t: max(1.0, t.abs().max().item())
+    close(wg.grad, wr.grad, 1e-4, 1e-4 * scale(wr.grad))
+    close(bg.grad, br.grad, 1e-4, 1e-4 * scale(br.grad))
+    y2, x2, stats = ops.layernorm_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), 1e-5, dt_out)
+    assert torch.equal(y2, got.detach())
+    _, dg2, db2 = ops.layernorm_bwd(dy.to(DEV), x2, stats, w.to(DEV), 1e-5)
+    assert torch.equal(dg2, wg.grad) and torch.equal(db2, bg.grad)
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
