@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--frames", type=int, default=2000)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--config", default="conmamba_large_ctc")
+ap.add_argument("--op-profile", action="store_true", help="one more step under torch.profiler: top ops by GPU time with input shapes")
 a = ap.parse_args()
 dev = torch.device("cuda")
 cfg = CONFIGS[a.config]
@@ -56,3 +57,15 @@ dt = (time.perf_counter() - t0) / a.steps
 print(f"{cfg.name} train step: batch {a.batch} x {a.frames} frames, {dt*1e3:.1f} ms/step, {a.batch*a.frames/dt/1e3:.1f} k audio-frames/s, "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, loss {losses[0]:.2f} -> {losses[-1]:.2f}, optimizer steps {brain.optimizer_step}")
 assert all(l == l for l in losses) and losses[-1] < losses[0], "loss did not decrease"
+
+if a.op_profile:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        brain.fit_batch(batch)
+        torch.cuda.synchronize()
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=45,
+                                                             max_shapes_column_width=70))
+    print("copies by input shape (GPU time, calls, shapes):")
+    for ev in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.device_time_total):
+        if any(k in ev.key for k in ("copy_", "contiguous", "clone", "aten::to", "_to_copy")) and ev.device_time_total > 200:
+            print(f"  {ev.key:24s} {ev.device_time_total / 1e3:8.2f} ms {ev.count:5d}  {ev.input_shapes}")
