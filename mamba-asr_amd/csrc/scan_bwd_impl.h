@@ -76,7 +76,9 @@ template <int S> __device__ __forceinline__ float row_channel_sum(float v) {
 }
 
 template <typename IO, typename BC, int S, int NS, bool REV>
-__global__ __launch_bounds__(kBwdThreads) void scan_bwd_kernel(const cm_scan_bwd_args p, int vecok) {
+// Two waves per SIMD (<= 256 VGPRs) where that costs few spills: NS = 2 spills 25-39 registers and runs 526 us instead
+// of 714 us per direction at 32 x 512 channels x 1000 steps; NS = 4 would spill 190 (940 us vs 572 us) and keeps one wave.
+__global__ __launch_bounds__(kBwdThreads, NS <= 2 ? 2 : 1) void scan_bwd_kernel(const cm_scan_bwd_args p, int vecok) {
     static_assert(S == 4 || S == 8 || S == 16, "backward supports lane splits 4, 8, 16");
     constexpr int N = S * NS;
     constexpr int CPW = 64 / S;
