@@ -274,6 +274,8 @@ def lib():
         got = handle.cm_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError(f"libconmamba_hip ABI {got} != binding {ABI_VERSION}: rebuild the library")
+        if os.environ.get("CM_DEBUG"):      # timing-only kernel variants (cm_debug_set), for A/B runs of whole programs
+            handle.cm_debug_set(int(os.environ["CM_DEBUG"]))
         _lib = handle
     return _lib
 

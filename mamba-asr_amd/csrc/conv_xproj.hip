@@ -14,13 +14,16 @@
 // HBM traffic: x once (+ a 6-row halo per 16, served by the XCD's L2), u twice E per step written, 192 B of x_dbl per step.
 #include "cm_common.h"
 
+extern "C" int cm_debug_get();
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int TT = 16;          // steps per workgroup
-constexpr int TH = TT / 2;      // steps per thread
+// steps per workgroup: TT (template), steps per thread TT / 2.  TT = 32 streams each x_proj weight fragment from L2 once per
+// TWO token tiles (at TT = 16 the 96 KB of weights per workgroup are more L2 traffic than the kernel's HBM bytes) and reads
+// 22 rows per 16 outputs instead of 14 per 8; its LDS tiles (67 KB) leave two workgroups per CU.
 constexpr int W = 4;            // conv width
 constexpr int NP = 48;          // x_dbl columns per direction
 constexpr int PF = 8;           // weight-fragment ring depth
@@ -34,7 +37,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 }
 __device__ __forceinline__ float silu(float a) { return a * cm_sigmoid(a); }
 
-__global__ __launch_bounds__(256, 4) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile) {
+template <int TT>
+__global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile) {
+    constexpr int TH = TT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int E = p.dim, T = p.seqlen;
     const int XS = E + 16;                                        // LDS row stride in bf16 elements
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(256, 4) void conv_xproj_kernel(const cm_conv_xproj_
 
     // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]; one wave per direction (48 MFMAs)
     if (wave >= 2) return;
-    const int dir = wave, nt = 0;
+    const int dir = wave;
+    constexpr int NTL = TT / 16;                                  // token tiles per workgroup
     const int l15 = lane & 15, lq = lane >> 4;
     const int nks = E / 32;
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -121,28 +127,57 @@ __global__ __launch_bounds__(256, 4) void conv_xproj_kernel(const cm_conv_xproj_
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) wload(s, wq[s]);                 // past-the-end fragments read as zeros (buffer bounds)
-    f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const uint16_t *frag = ut[dir] + (16 * nt + l15) * XS + lq * 8;
+    f32x4 acc[NTL][3];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint16_t *frag = ut[dir] + l15 * XS + lq * 8;
     for (int ks0 = 0; ks0 < nks; ks0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const int ks = ks0 + s;
             if (ks < nks) {
-                const bf16x8 tok = *reinterpret_cast<const bf16x8 *>(frag + ks * 32);
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][mt], tok, acc[mt], 0, 0, 0);
+                for (int nt = 0; nt < NTL; ++nt) {
+                    const bf16x8 tok = *reinterpret_cast<const bf16x8 *>(frag + nt * 16 * XS + ks * 32);
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][mt], tok, acc[nt][mt], 0, 0, 0);
+                }
                 wload(ks + PF, wq[s]);
             }
         }
     }
-    const int t = t0 + 16 * nt + l15;
-    if (t < T) {
-        uint16_t *xo = reinterpret_cast<uint16_t *>(p.xdbl) + (int64_t)b * p.xdbl_bs + (int64_t)t * p.xdbl_ts + dir * NP + lq * 4;
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
-            *reinterpret_cast<uint2 *>(xo + mt * 16) = uint2{pack2(acc[mt][0], acc[mt][1]), pack2(acc[mt][2], acc[mt][3])};
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int t = t0 + 16 * nt + l15;
+        if (t < T) {
+            uint16_t *xo = reinterpret_cast<uint16_t *>(p.xdbl) + (int64_t)b * p.xdbl_bs + (int64_t)t * p.xdbl_ts + dir * NP + lq * 4;
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+                *reinterpret_cast<uint2 *>(xo + mt * 16) = uint2{pack2(acc[nt][mt][0], acc[nt][mt][1]), pack2(acc[nt][mt][2], acc[nt][mt][3])};
+        }
     }
+}
+
+template <int TT>
+int launch_cx(const cm_conv_xproj_args &a) {
+    const size_t smem = (size_t)2 * TT * (a.dim + 16) * sizeof(uint16_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_xproj_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) {
+            cm_set_error("conv_xproj: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_done = true;
+    }
+    const int ntile = (a.seqlen + TT - 1) / TT;
+    CM_REQUIRE((long)ntile * a.batch < (1L << 31), CM_EINVAL, "conv_xproj: grid too large");
+    hipLaunchKernelGGL(conv_xproj_kernel<TT>, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile);
+    return cm_launch_status("cm_conv_xproj");
 }
 
 }  // namespace
@@ -159,19 +194,7 @@ extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
                    a.x_bs % 4 == 0 && a.x_ts % 4 == 0 && a.yf_bs % 4 == 0 && a.yf_ts % 4 == 0 && a.yb_bs % 4 == 0 &&
                    a.yb_ts % 4 == 0 && a.xdbl_bs % 4 == 0 && a.xdbl_ts % 4 == 0,
                CM_EALIGN, "conv_xproj: tensors must be 8-byte aligned (weights 16) with strides that are multiples of 4 elements");
-    const size_t smem = (size_t)2 * TT * (a.dim + 16) * sizeof(uint16_t);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_xproj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) {
-            cm_set_error("conv_xproj: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_done = true;
-    }
-    const int ntile = (a.seqlen + TT - 1) / TT;
-    CM_REQUIRE((long)ntile * a.batch < (1L << 31), CM_EINVAL, "conv_xproj: grid too large");
-    hipLaunchKernelGGL(conv_xproj_kernel, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile);
-    return cm_launch_status("cm_conv_xproj");
+    // 32-step tiles when the LDS tiles fit twice per CU and the sequence is long enough to fill the chip with them
+    const bool wide = cm_debug_get() != 16 && (size_t)2 * 32 * (a.dim + 16) * 2 <= 72 * 1024 && (long)a.batch * ((a.seqlen + 31) / 32) >= 512;
+    return wide ? launch_cx<32>(a) : launch_cx<16>(a);
 }

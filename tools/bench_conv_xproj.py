@@ -20,6 +20,25 @@ for b in (16, 32, 64):
     ucat = torch.empty(b, l, 2 * e, device=dev, dtype=torch.bfloat16)
     xdbl = torch.empty(b, l, 96, device=dev, dtype=torch.bfloat16)
     t1 = timeit(lambda: ops.conv_xproj(x, wf, bf, wb, bb, pk[0], pk[1], out_f=ucat[:, :, :e], out_b=ucat[:, :, e:], xdbl=xdbl))
+    # the same call cycling through buffer sets whose total exceeds the 256 MB memory-side cache: what the kernel sees in the
+    # encoder, where its input was written and its output is read by other kernels with ~1 GB of traffic in between
+    from mamba_asr_amd import _native
+    nset = max(2, int(1.2e9 / (b * l * (2 * e * 2 * 2 + 192))))
+    sets = [(torch.randn(b, l, 2 * e, device=dev).bfloat16(), torch.empty(b, l, 2 * e, device=dev, dtype=torch.bfloat16),
+             torch.empty(b, l, 96, device=dev, dtype=torch.bfloat16)) for _ in range(nset)]
+    state = {"i": 0}
+
+    def cold():
+        xs, us, xd = sets[state["i"] % nset]
+        state["i"] += 1
+        ops.conv_xproj(xs[:, :, :e], wf, bf, wb, bb, pk[0], pk[1], out_f=us[:, :, :e], out_b=us[:, :, e:], xdbl=xd)
+    res = []
+    for dbg in (0, 16, 0, 16):
+        _native.lib().cm_debug_set(dbg)
+        res.append(timeit(cold, iters=4 * nset))
+    _native.lib().cm_debug_set(0)
+    print(f"B={b}: cold buffers ({nset} sets): default tile {res[0]:6.1f} / {res[2]:6.1f} us, 16-step tile {res[1]:6.1f} / {res[3]:6.1f} us", flush=True)
+    del sets
     t2 = timeit(lambda: ops.conv_cl_fwd(x, wf, bf, wb, bb, True, out_f=ucat[:, :, :e], out_b=ucat[:, :, e:]))
     t3 = timeit(lambda: torch.matmul(ucat.view(-1, 2 * e), wbd.t()))
     mb = b * l * (e * 2 + 2 * e * 2 + 192) / 1e6
