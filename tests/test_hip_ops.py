@@ -290,10 +290,12 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     close(got.float(), ref.transpose(1, 2), *((2e-3, 1e-4) if dtype == torch.float32 else (1.6e-2, 2e-2)))   # growing states: looser rtol
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 512), (2, 5, 96), (1, 33, 1024)])
+@pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 512), (2, 5, 96), (1, 33, 1024), (16, 1000, 512), (40, 403, 288)])
 def test_conv_xproj(ops, shape):
     """cm_conv_xproj == cm_conv_cl_fwd (bit-exact u) and x_dbl rows == u @ Wx^T computed in fp32 from the bf16 u and
-    bf16 weights (the products the MFMA forms), within bf16 output rounding; x a column slice of a wider [x | z]."""
+    bf16 weights (the products the MFMA forms), within bf16 output rounding; x a column slice of a wider [x | z].
+    The last two shapes are large enough for the 32-step tiles (ragged last tile in the second); the 16-step tiles on
+    the same input must give the same bits."""
     b, l, e = shape
     gen = torch.Generator().manual_seed(l + e)
     xz = torch.randn(b, l, 2 * e, generator=gen).bfloat16().to(DEV)
@@ -311,6 +313,15 @@ def test_conv_xproj(ops, shape):
     for i, u in enumerate((rf, rb)):
         want = u.float() @ wx[i].float().t()
         close(xdbl[:, :, 48 * i:48 * (i + 1)].float(), want, 1.6e-2, 2e-2)
+    if b * ((l + 31) // 32) >= 512:
+        from mamba_asr_amd import _native
+        u16 = torch.zeros_like(ucat)
+        _native.lib().cm_debug_set(16)
+        try:
+            x16 = ops.conv_xproj(x, wf, bf, wb, bb, ops.PackedWeight(wx[0]), ops.PackedWeight(wx[1]), out_f=u16[:, :, :e], out_b=u16[:, :, e:])
+        finally:
+            _native.lib().cm_debug_set(0)
+        assert torch.equal(u16, ucat) and torch.equal(x16, xdbl)
 
 
 def test_scan_rows_extreme_time_steps(ops):
