@@ -45,8 +45,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 }
 
 // VAR (cm_debug_set, timing only): 1 = scalar GELU (cm_gelu_bf16 per element; 108-110 us vs 99-100 us packed at 64k rows), 2 = no GELU, 3 = no weight stream after the first fill,
-// 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4, 6 / 7 = workgroups of the second occupancy slot
-// (ids 256..511 of each 512) start 3.4 / 10 us late so that a CU's two workgroups are in different phases
+// 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4.  (Starting the workgroups of the second occupancy slot
+// 3.4 / 10 us late, so that a CU's two workgroups are in different phases, was also tried: no effect.)
 template <bool ADD, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -56,10 +56,6 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     float *b1s = red + 4 * TOK;                                   // [hidden] first bias (a global load inside the slab
                                                                   // loop would wait on vmcnt and drain the weight ring)
     const int tid = threadIdx.x, lane = tid & 63;
-    if constexpr (VAR == 6 || VAR == 7) {
-        if ((blockIdx.x >> 8) & 1)
-            for (int i = 0; i < (VAR == 6 ? 1 : 3); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 4*TH-1: owns tokens 16 wv .. +15 in the LayerNorm phases
     const int wave = wv & 3;                                      // feature quarter (uniform: feeds the buffer loads' scalar offset)
     const int th = wv >> 2;                                       // token half in the GEMMs / epilogue
@@ -387,8 +383,6 @@ int launch(const cm_ffn_args &a) {
         case 3: return launch_var<ADD, 3>(a);
         case 4: return launch_var<ADD, 4>(a);
         case 5: return launch_var<ADD, 5>(a);
-        case 6: return launch_var<ADD, 6>(a);
-        case 7: return launch_var<ADD, 7>(a);
         default: return launch_var<ADD, 0>(a);
     }
 }
