@@ -409,7 +409,8 @@ int cm_dwconv_cl_bwd(const cm_dwconv_cl_args *args);
  * LayerNorm behind the reference's normalisations: modules/Conmamba.py:262, :287 (ConvolutionModule), :597-620
  * (feed-forward pre-norms, norm1, norm2), :687 (final norm) -- under autocast torch runs them in fp32 whatever the
  * input type, so x may be bf16 while y is fp32.
- *   fwd: y = (x - mean) * rstd * gamma + beta over rows of `dim` (multiple of 4, <= 1024), contiguous; mean / rstd
+ *   fwd: y = (x - mean) * rstd * gamma + beta over rows of `dim` (multiple of 4, <= 4096: the CNN front end normalises
+ *        over (frequency, channel) = 2560), contiguous; mean / rstd
  *        (rows) fp32 are written when given (both or neither).
  *   bwd: dx (x_dtype, may be NULL) and dgamma / dbeta (dim, OVERWRITTEN) from dy (y_dtype), x, mean, rstd, gamma;
  *        workspace: cm_layernorm_bwd_workspace_floats(rows, dim) fp32, caller-owned; fixed summation order.

@@ -178,6 +178,119 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
     }
 }
 
+// ---- rows wider than 1024 (the CNN front end's LayerNorm over (frequency, channel): 40 x 64 = 2560): one workgroup of 256
+// threads per row, thread t owns the 4-column groups t + 256 i; row statistics are block reductions (one barrier each,
+// alternating scratch slots), the column sums stay in the thread's registers across the rows its workgroup walks.
+__device__ __forceinline__ float block_sum(float v, float (*sh)[4], int &phase) {
+    v = cm_group_sum<16>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    float *slot = sh[phase & 1];
+    phase ^= 1;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+}
+
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const cm_layernorm_args p) {
+    __shared__ float sh[2][4];
+    int phase = 0;
+    const int dim = p.dim, t = threadIdx.x;
+    const float inv = 1.0f / dim;
+    const XT *x = reinterpret_cast<const XT *>(p.x);
+    YT *y = reinterpret_cast<YT *>(p.y);
+    bool on[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) on[i] = 4 * (t + 256 * i) < dim;
+    for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
+        float4 v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            v[i] = on[i] ? ld4<XT>(x + row * dim + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = block_sum(s, sh, phase) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (on[i]) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                q = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, q))));
+            }
+        }
+        const float rstd = rsqrtf(block_sum(q, sh, phase) * inv + p.eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (on[i]) {
+                const int c = 4 * (t + 256 * i);
+                const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c), b = *reinterpret_cast<const float4 *>(p.beta + c);
+                st4(y + row * dim + c, make_float4(fmaf(v[i].x * rstd, g.x, b.x), fmaf(v[i].y * rstd, g.y, b.y),
+                                                   fmaf(v[i].z * rstd, g.z, b.z), fmaf(v[i].w * rstd, g.w, b.w)));
+            }
+        }
+        if (t == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
+    }
+}
+
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const cm_layernorm_args p) {
+    __shared__ float sh[2][4];
+    int phase = 0;
+    const int dim = p.dim, t = threadIdx.x;
+    const float inv = 1.0f / dim;
+    const XT *x = reinterpret_cast<const XT *>(p.x);
+    const YT *dy = reinterpret_cast<const YT *>(p.dy);
+    XT *dx = reinterpret_cast<XT *>(p.dx);
+    bool on[MAXV];
+    float4 dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        on[i] = 4 * (t + 256 * i) < dim;
+        dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        float4 xh[MAXV], gy[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on[i]) {
+                const int c = 4 * (t + 256 * i);
+                const float4 v = ld4<XT>(x + row * dim + c), d = ld4<YT>(dy + row * dim + c);
+                const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c);
+                xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+                gy[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                dg[i].x = fmaf(d.x, xh[i].x, dg[i].x); dg[i].y = fmaf(d.y, xh[i].y, dg[i].y);
+                dg[i].z = fmaf(d.z, xh[i].z, dg[i].z); dg[i].w = fmaf(d.w, xh[i].w, dg[i].w);
+                db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+            }
+            s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+            s2 = fmaf(gy[i].x, xh[i].x, fmaf(gy[i].y, xh[i].y, fmaf(gy[i].z, xh[i].z, fmaf(gy[i].w, xh[i].w, s2))));
+        }
+        const float c1 = block_sum(s1, sh, phase) * inv, c2 = block_sum(s2, sh, phase) * inv;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (on[i])
+                    st4(dx + row * dim + 4 * (t + 256 * i),
+                        make_float4(rstd * (gy[i].x - c1 - xh[i].x * c2), rstd * (gy[i].y - c1 - xh[i].y * c2),
+                                    rstd * (gy[i].z - c1 - xh[i].z * c2), rstd * (gy[i].w - c1 - xh[i].w * c2)));
+            }
+        }
+    }
+    float *part = p.workspace + (int64_t)blockIdx.x * 2 * dim;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (on[i]) {
+            st4(part + 4 * (t + 256 * i), dg[i]);
+            st4(part + dim + 4 * (t + 256 * i), db[i]);
+        }
+    }
+}
+
 // dgamma | dbeta (2*dim columns) = sum over the partial rows, fixed order: 32 columns x 8 row groups per workgroup
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nblk, int dim,
                                                            float *__restrict__ dgamma, float *__restrict__ dbeta) {
@@ -199,7 +312,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
 
 int check(const cm_layernorm_args &a, const char *what) {
     CM_REQUIRE(a.rows > 0 && a.dim > 0 && a.x && a.gamma, CM_EINVAL, "%s: bad sizes or NULL tensor", what);
-    CM_REQUIRE(a.dim % 4 == 0 && a.dim <= 1024, CM_EUNSUPPORTED, "%s: dim must be a multiple of 4, at most 1024 (got %d)", what, a.dim);
+    CM_REQUIRE(a.dim % 4 == 0 && a.dim <= 4096, CM_EUNSUPPORTED, "%s: dim must be a multiple of 4, at most 4096 (got %d)", what, a.dim);
     CM_REQUIRE((a.x_dtype == CM_F32 || a.x_dtype == CM_BF16) && (a.y_dtype == CM_F32 || a.y_dtype == CM_BF16), CM_EUNSUPPORTED,
                "%s: dtypes must be f32 or bf16", what);
     CM_REQUIRE(cm_aligned(a.x, 16) && cm_aligned(a.gamma, 16), CM_EALIGN, "%s: tensors must be 16-byte aligned", what);
@@ -209,6 +322,25 @@ int check(const cm_layernorm_args &a, const char *what) {
 int grid_for(int64_t rows, int rpw, int nt, int cap) {
     const int64_t need = (rows + (int64_t)rpw * (nt / 64) - 1) / ((int64_t)rpw * (nt / 64));
     return (int)(need < cap ? need : cap);
+}
+
+template <typename XT, typename YT>
+int launch_wide(const cm_layernorm_args &a, bool bwd) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    if (!bwd) {
+        hipLaunchKernelGGL((ln_fwd_wide_kernel<XT, YT>), dim3((unsigned)(a.rows < 4096 ? a.rows : 4096)), dim3(256), 0, st, a);
+        return cm_launch_status("cm_layernorm_fwd");
+    }
+    const int nblk = (int)(a.rows < BWD_BLOCKS ? a.rows : BWD_BLOCKS);
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<XT, YT>), dim3(nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.dim + 31) / 32), dim3(256), 0, st, a.workspace, nblk, a.dim, a.dgamma, a.dbeta);
+    return cm_launch_status("cm_layernorm_bwd");
+}
+
+int dispatch_wide(const cm_layernorm_args &a, bool bwd) {
+    const bool xb = a.x_dtype == CM_BF16, yb = a.y_dtype == CM_BF16;
+    if (xb) return yb ? launch_wide<cm_bf16, cm_bf16>(a, bwd) : launch_wide<cm_bf16, float>(a, bwd);
+    return yb ? launch_wide<float, cm_bf16>(a, bwd) : launch_wide<float, float>(a, bwd);
 }
 
 template <template <int, typename, typename> class Launch>
@@ -252,7 +384,7 @@ extern "C" int cm_layernorm_fwd(const cm_layernorm_args *args) {
     if (int rc = check(a, "layernorm_fwd")) return rc;
     CM_REQUIRE(a.beta && a.y && (!a.mean == !a.rstd), CM_EINVAL, "layernorm_fwd: beta / y must be non-NULL, mean and rstd given together");
     CM_REQUIRE(cm_aligned(a.beta, 16) && cm_aligned(a.y, 16), CM_EALIGN, "layernorm_fwd: tensors must be 16-byte aligned");
-    return dispatch<FwdLaunch>(a);
+    return a.dim > 1024 ? dispatch_wide(a, false) : dispatch<FwdLaunch>(a);
 }
 
 extern "C" int cm_layernorm_bwd(const cm_layernorm_args *args) {
@@ -262,5 +394,5 @@ extern "C" int cm_layernorm_bwd(const cm_layernorm_args *args) {
     CM_REQUIRE(a.dy && a.mean && a.rstd && a.dgamma && a.dbeta && a.workspace, CM_EINVAL,
                "layernorm_bwd: dy / mean / rstd / dgamma / dbeta / workspace must be non-NULL");
     CM_REQUIRE(cm_aligned(a.dy, 16) && (!a.dx || cm_aligned(a.dx, 16)), CM_EALIGN, "layernorm_bwd: tensors must be 16-byte aligned");
-    return dispatch<BwdLaunch>(a);
+    return a.dim > 1024 ? dispatch_wide(a, true) : dispatch<BwdLaunch>(a);
 }

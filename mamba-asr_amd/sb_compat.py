@@ -31,15 +31,21 @@ USE_NATIVE_LN = os.environ.get("CM_NATIVE_LN", "1") == "1"
 
 
 class RowsLayerNorm(nn.LayerNorm):
-    """nn.LayerNorm (same parameters and state_dict keys) whose GPU forward/backward over a single normalised axis run
-    on the native kernels; other shapes (the CNN front end's (freq, channel) norm) and CPU tensors take torch's path."""
+    """nn.LayerNorm (same parameters and state_dict keys) whose GPU forward/backward run on the native kernels (rows of up
+    to 4096 normalised elements, contiguous); anything else and CPU tensors take torch's path."""
 
     def forward(self, x):
-        if (USE_NATIVE_LN and x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
-                and self.normalized_shape[0] % 4 == 0 and self.normalized_shape[0] <= 1024
-                and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
+        dim = math.prod(self.normalized_shape)
+        if (USE_NATIVE_LN and x.is_cuda and self.weight is not None and self.bias is not None and dim % 4 == 0 and dim <= 4096
+                and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0
+                and (len(self.normalized_shape) == 1 or x.is_contiguous())):
             from . import ops
-            return ops.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+            if len(self.normalized_shape) == 1:
+                return ops.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+            # several trailing axes (the CNN front end's (frequency, channel) norm): rows of their product
+            lead = x.shape[:x.dim() - len(self.normalized_shape)]
+            y = ops.LayerNormFn.apply(x.reshape(*lead, dim), self.weight.reshape(dim), self.bias.reshape(dim), self.eps)
+            return y.view(x.shape)
         return super().forward(x)
 
 

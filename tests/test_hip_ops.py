@@ -447,6 +447,38 @@ def test_layernorm_forward_backward(ops, shape, mode):
     assert torch.equal(dg2, wg.grad) and torch.equal(db2, bg.grad)
 
 
+@pytest.mark.parametrize("shape,norm", [((2, 50, 40, 64), (40, 64)), ((3, 33, 20, 32), (20, 32)), ((1, 7, 4096), (4096,)), ((2, 9, 1028), (1028,))])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_layernorm_module_wide_and_multi_axis(ops, shape, norm, autocast):
+    """sb_compat.RowsLayerNorm (the module every LayerNorm of the module API is) over several trailing axes and over rows
+    wider than 1024 (one workgroup per row) vs torch's LayerNorm in float64: the CNN front end's (frequency, channel)
+    norms (40 x 64 = 2560, 20 x 32 = 640), the 4096 limit, a width that leaves threads idle."""
+    from mamba_asr_amd import sb_compat as sb
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=gen) * 1.5 + 0.3).to(torch.bfloat16 if autocast else torch.float32)
+    dy = torch.randn(*shape, generator=gen)
+    m = sb.RowsLayerNorm(norm, eps=1e-5)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(*norm, generator=gen) * 0.5 + 1.0)
+        m.bias.copy_(torch.randn(*norm, generator=gen) * 0.2)
+    ref_m = torch.nn.LayerNorm(norm, eps=1e-5).double()
+    ref_m.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    ref = ref_m(xr)
+    ref.backward(dy.double())
+    m = m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        got = m(xg)
+    assert got.dtype == torch.float32 and got.shape == x.shape
+    got.backward(dy.to(DEV))
+    close(got, ref, 1e-5, 2e-5)
+    close(xg.grad.float(), xr.grad, *((1.6e-2, 1e-2) if autocast else (1e-4, 1e-4)))
+    scale = lambda t: max(1.0, t.abs().max().item())
+    close(m.weight.grad, ref_m.weight.grad, 1e-4, 1e-4 * scale(ref_m.weight.grad))
+    close(m.bias.grad, ref_m.bias.grad, 1e-4, 1e-4 * scale(ref_m.bias.grad))
+
+
 @pytest.mark.parametrize("shape", [(100, 256, 256), (777, 1024, 256), (130, 256, 1024), (64, 512, 640)])
 def test_gemm_bf16_epilogues(ops, shape):
     """cm_gemm_bf16 vs torch fp32 reference on the same bf16-rounded operands; asymmetric data so that a transposed
