@@ -297,8 +297,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
     __shared__ float red[8][32];
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float s = 0.f;
-    if (col < 2 * dim)
-        for (int b = grp; b < nblk; b += 8) s += part[(int64_t)b * 2 * dim + col];
+    if (col < 2 * dim) {
+#pragma unroll 8
+        for (int b = grp; b < nblk; b += 8) s += part[(int64_t)b * 2 * dim + col];     // unrolled: 8 loads in flight per thread
+    }
     red[grp][threadIdx.x & 31] = s;
     __syncthreads();
     if (grp == 0 && col < 2 * dim) {

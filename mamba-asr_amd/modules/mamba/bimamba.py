@@ -31,9 +31,10 @@ class _InProjFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, hidden, weight):
         batch, seqlen, _ = hidden.shape
-        ctx.save_for_backward(hidden, weight)
         w = weight.to(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else weight
-        xz = (w @ hidden.reshape(batch * seqlen, -1).to(w.dtype).t()).reshape(-1, batch, seqlen)
+        hidden = hidden.to(w.dtype)                         # cast once; the backward's weight gradient reuses it
+        ctx.save_for_backward(hidden, weight)
+        xz = (w @ hidden.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen)
         return xz.transpose(0, 1)
 
     @staticmethod

@@ -71,7 +71,9 @@ class _LinearRowsFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype("cuda"))     # the cast autocast would make inside F.linear, made once: the
+        ctx.save_for_backward(x, weight)                    # backward reuses it (and the fp32 input need not stay alive)
         ctx.has_bias = bias is not None
         return F.linear(x, weight, bias)
 
