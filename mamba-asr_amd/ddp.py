@@ -62,7 +62,7 @@ class GradAllReducer:
                 p.register_post_accumulate_grad_hook(self._hook)
         if broadcast_from is not None and self.world > 1:      # DDP broadcasts parameters when it wraps a module
             for p in self.params:
-                dist.broadcast(p.data, src=broadcast_from, group=self.group)
+                dist.broadcast(p.detach(), src=broadcast_from, group=self.group)   # detach(): shares the version counter (ops.cast_cached)
 
     # ---- autograd side -------------------------------------------------------------------
     def _hook(self, p):

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from .selective_scan_interface import (bimamba_inner_fn, causal_conv1d_fn, mamba_inner_fn,
                                        mamba_inner_fn_no_out_proj, selective_scan_fn)
 
@@ -31,7 +32,7 @@ class _InProjFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, hidden, weight):
         batch, seqlen, _ = hidden.shape
-        w = weight.to(torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else weight
+        w = ops.cast_cached(weight, torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else weight
         hidden = hidden.to(w.dtype)                         # cast once; the backward's weight gradient reuses it
         ctx.save_for_backward(hidden, weight)
         xz = (w @ hidden.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen)
@@ -45,7 +46,7 @@ class _InProjFn(torch.autograd.Function):
         flat = dxz.permute(1, 0, 2).reshape(dxz.shape[1], batch * seqlen)       # a view when dxz has xz's layout
         dh = dw = None
         if ctx.needs_input_grad[0]:
-            dh = (flat.t() @ weight.to(flat.dtype)).view(batch, seqlen, -1)
+            dh = (flat.t() @ ops.cast_cached(weight, flat.dtype)).view(batch, seqlen, -1)
         if ctx.needs_input_grad[1]:
             dw = torch.bmm(dxz, hidden.to(dxz.dtype)).sum(0)
         return dh, dw
@@ -61,7 +62,7 @@ class _OutProjFn(torch.autograd.Function):
         batch, e, seqlen = mix.shape
         ctx.save_for_backward(mix, weight)
         ctx.has_bias = bias is not None
-        w = weight.to(mix.dtype)
+        w = ops.cast_cached(weight, mix.dtype)
         y = torch.mm(mix.permute(1, 0, 2).reshape(e, batch * seqlen).t(), w.t())
         if bias is not None:
             y = y + bias.to(y.dtype)
@@ -75,7 +76,7 @@ class _OutProjFn(torch.autograd.Function):
         dy = dy.to(mix.dtype)
         dmix = dw = db = None
         if ctx.needs_input_grad[0]:
-            dmix = (weight.t().to(dy.dtype) @ dy.reshape(batch * seqlen, -1).t()).view(e, batch, seqlen).transpose(0, 1)
+            dmix = (ops.cast_cached(weight, dy.dtype).t() @ dy.reshape(batch * seqlen, -1).t()).view(e, batch, seqlen).transpose(0, 1)
         if ctx.needs_input_grad[1]:
             dw = torch.bmm(dy.transpose(1, 2), mix.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:

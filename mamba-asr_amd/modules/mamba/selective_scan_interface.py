@@ -104,7 +104,7 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None, *, reverse_time=Fals
 def _cast_autocast(*ws):
     if torch.is_autocast_enabled("cuda"):
         dt = torch.get_autocast_dtype("cuda")
-        return tuple(None if w is None else w.to(dt) for w in ws)
+        return tuple(None if w is None else ops.cast_cached(w, dt) for w in ws)
     return ws
 
 

@@ -36,6 +36,23 @@ def _launch(name: str, fn, args, units: int = 0):
     log.append((name, e0, e1, units))
 
 
+def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """p in `dtype`, without autograd, cached on the tensor until it is modified in place (optimizer step, load_state_dict,
+    broadcast): the autograd nodes of this package use a weight's bf16 copy in forward AND backward, several times per
+    step, and autocast's own cache does not reach into custom Functions."""
+    if p.dtype == dtype:
+        return p.detach()
+    c = getattr(p, "_cm_cast", None)
+    if c is not None and c[0] == p._version and c[1].dtype == dtype and c[1].device == p.device:
+        return c[1]
+    t = p.detach().to(dtype)
+    try:
+        p._cm_cast = (p._version, t)
+    except (AttributeError, RuntimeError):
+        pass
+    return t
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 

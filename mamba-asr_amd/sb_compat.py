@@ -83,7 +83,8 @@ class _LinearRowsFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy, weight.to(dy.dtype))
+            from . import ops
+            dx = torch.matmul(dy, ops.cast_cached(weight, dy.dtype))
         if ctx.needs_input_grad[1]:
             if x.dim() == 3 and x.shape[0] > 1:
                 dw = torch.bmm(dy.transpose(1, 2), x.to(dy.dtype)).sum(0)

@@ -61,3 +61,24 @@ def test_ops_refuse_cpu_tensors(native):
     x = torch.zeros(1, 8, 16)
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.causal_conv1d_fwd(x, torch.zeros(8, 4))
+
+
+def test_cast_cache_follows_in_place_updates(native):
+    """ops.cast_cached (the bf16 weight copies the autograd nodes reuse within a step) must notice every in-place
+    update of the parameter: optimizer steps, copy_ (load_state_dict) and updates through detach()."""
+    import torch
+    from mamba_asr_amd import ops
+    p = torch.nn.Parameter(torch.randn(8, 8))
+    c1 = ops.cast_cached(p, torch.bfloat16)
+    assert ops.cast_cached(p, torch.bfloat16) is c1 and not c1.requires_grad
+    opt = torch.optim.SGD([p], lr=0.5)
+    p.grad = torch.ones_like(p)
+    opt.step()
+    c2 = ops.cast_cached(p, torch.bfloat16)
+    assert c2 is not c1 and torch.equal(c2, p.detach().bfloat16())
+    with torch.no_grad():
+        p.copy_(torch.zeros(8, 8))
+    assert torch.equal(ops.cast_cached(p, torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+    p.detach().add_(1.0)
+    assert torch.equal(ops.cast_cached(p, torch.bfloat16), torch.ones(8, 8, dtype=torch.bfloat16))
+    assert ops.cast_cached(p, torch.float32).data_ptr() == p.data_ptr()
