@@ -10,6 +10,8 @@ import enum
 from types import SimpleNamespace
 from typing import Optional
 
+import os
+
 import torch
 
 from .ddp import GradAllReducer
@@ -60,6 +62,17 @@ class Brain:
         params = [p for p in self.modules.parameters() if p.requires_grad]
         if self.opt_class is not None and self.optimizer is None:
             self.optimizer = self.opt_class(params)
+            # the recipes build torch.optim.AdamW without `fused` (reference hparams/CTC/conmamba_large.yaml:248-252) and that
+            # is what runs by default.  CM_FUSED_ADAMW=1 switches GPU parameters to torch's fused multi-tensor kernel (~1 ms
+            # instead of ~6 ms of foreach kernels per step for 31.5 M parameters: 94.4 -> 91.1 ms per 32 x 40 s step); its
+            # fp32 on-device bias corrections do not reproduce the foreach path bit for bit (loss after 5 warm-up steps
+            # 2217.98 vs 2209.33), hence opt-in
+            opt = self.optimizer
+            if (isinstance(opt, (torch.optim.AdamW, torch.optim.Adam)) and os.environ.get("CM_FUSED_ADAMW", "0") == "1"
+                    and params and all(p.is_cuda for p in params) and not opt.state):
+                for g in opt.param_groups:
+                    if g.get("fused") is None and not g.get("capturable", False) and not g.get("differentiable", False):
+                        g["fused"], g["foreach"] = True, False
         if self.distributed and self.reducer is None:
             self.reducer = GradAllReducer(params)
 
