@@ -290,6 +290,69 @@ class Augmenter(nn.Module):
         return labels
 
 
+class Resample(nn.Module):
+    """speechbrain.processing.speech_augmentation.Resample (Kaldi's LinearResample): windowed-sinc polyphase resampling of
+    (batch, time) waveforms.  cutoff = 0.99 * 0.5 * min(orig, new); Hann-windowed sinc with `lowpass_filter_width` zero
+    crossings on each side; one FIR filter per output phase, applied as a strided conv1d; the output has
+    floor(len * new / orig) samples.  (speechbrain is absent here: restated from the published algorithm, parity unpinned;
+    tests pin its properties — identity at equal rates, tone frequency / amplitude / length after resampling.)"""
+
+    def __init__(self, orig_freq=16000, new_freq=16000, lowpass_filter_width=4):
+        super().__init__()
+        self.orig_freq, self.new_freq, self.width = int(orig_freq), int(new_freq), lowpass_filter_width
+        base = math.gcd(self.orig_freq, self.new_freq)
+        self.in_unit, self.out_unit = self.orig_freq // base, self.new_freq // base
+        if self.orig_freq == self.new_freq:
+            return
+        cutoff = 0.99 * 0.5 * min(self.orig_freq, self.new_freq)
+        window = lowpass_filter_width / (2.0 * cutoff)                       # half width of the filter in seconds
+        out_t = torch.arange(self.out_unit, dtype=torch.float64) / self.new_freq
+        first = torch.ceil((out_t - window) * self.orig_freq).long()         # first input sample each phase uses
+        taps = int(torch.max(torch.floor((out_t + window) * self.orig_freq).long() - first)) + 1
+        j = torch.arange(taps, dtype=torch.float64)[None, :]
+        dt = (first[:, None] + j) / self.orig_freq - out_t[:, None]
+        w = torch.where(dt.abs() < window, 0.5 * (1.0 + torch.cos(2 * math.pi * cutoff / lowpass_filter_width * dt)), torch.zeros_like(dt))
+        sinc = torch.where(dt == 0, torch.full_like(dt, 2 * cutoff), torch.sin(2 * math.pi * cutoff * dt) / (math.pi * dt))
+        self.register_buffer("weights", (w * sinc / self.orig_freq).float()[:, None, :], persistent=False)    # (phases, 1, taps)
+        self.first = [int(v) for v in first]
+
+    @torch.no_grad()
+    def forward(self, wav):
+        if self.orig_freq == self.new_freq:
+            return wav
+        squeeze = wav.dim() == 1
+        x = wav[None] if squeeze else wav
+        n = x.shape[-1]
+        n_out = n * self.new_freq // self.orig_freq
+        lo = min(self.first)                                               # most negative start (<= 0)
+        units = (n_out + self.out_unit - 1) // self.out_unit
+        taps = self.weights.shape[-1]
+        need = (units - 1) * self.in_unit + max(self.first) + taps
+        xp = F.pad(x.float(), (-lo, max(0, need - n)))
+        outs = []
+        for ph in range(self.out_unit):                                    # phase ph reads x[u * in_unit + first[ph] + j]
+            seg = xp[:, self.first[ph] - lo:]
+            outs.append(F.conv1d(seg[:, None, :], self.weights[ph:ph + 1].to(xp.device), stride=self.in_unit)[:, 0, :units])
+        y = torch.stack(outs, dim=-1).reshape(x.shape[0], -1)[:, :n_out].to(wav.dtype)
+        return y[0] if squeeze else y
+
+
+class SpeedPerturb(nn.Module):
+    """speechbrain.augment.time_domain.SpeedPerturb (reference hparams/CTC/conmamba_large.yaml:260-264, applied per
+    utterance in the data pipeline, train_CTC.py:932-934): one of `speeds` (percent) drawn per call; the waveform is
+    resampled from orig_freq to orig_freq * speed // 100 and then treated as orig_freq audio."""
+
+    def __init__(self, orig_freq, speeds=(90, 100, 110), device="cpu"):
+        super().__init__()
+        self.orig_freq, self.speeds = orig_freq, list(speeds)
+        self.resamplers = nn.ModuleList(Resample(orig_freq, orig_freq * sp // 100) for sp in self.speeds)
+        self.samp_index = 0
+
+    def forward(self, waveform):
+        self.samp_index = int(torch.randint(len(self.speeds), (1,)))
+        return self.resamplers[self.samp_index](waveform)
+
+
 class _ConvLayer(nn.Module):
     def __init__(self, cin, cout, freq, kernel, stride, dropout):
         super().__init__()
