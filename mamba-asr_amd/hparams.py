@@ -25,6 +25,8 @@ _SB_MAP = {
     "speechbrain.lobes.features.Fbank": "mamba_asr_amd.sb_compat.Fbank",
     "speechbrain.augment.freq_domain.SpectrogramDrop": "mamba_asr_amd.sb_compat.SpectrogramDrop",
     "speechbrain.augment.augmenter.Augmenter": "mamba_asr_amd.sb_compat.Augmenter",
+    "speechbrain.augment.time_domain.SpeedPerturb": "mamba_asr_amd.sb_compat.SpeedPerturb",
+    "speechbrain.nnet.losses.kldiv_loss": "mamba_asr_amd.sb_compat.kldiv_loss",
     "speechbrain.nnet.losses.ctc_loss": "mamba_asr_amd.sb_compat.ctc_loss",
     "speechbrain.nnet.schedulers.NoamScheduler": "mamba_asr_amd.sb_compat.NoamScheduler",
     "speechbrain.nnet.activations.Swish": "mamba_asr_amd.sb_compat.Swish",

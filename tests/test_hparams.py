@@ -46,3 +46,5 @@ def test_reference_large_ctc_yaml_loads_unmodified():
     tr = hp["Transformer"]
     assert sum(p.numel() for p in tr.parameters()) == 31_522_048                # 31.52 M
     assert hp["grad_accumulation_factor"] == 4 and hp["precision"] == "bf16"
+    from mamba_asr_amd import sb_compat as sb
+    assert isinstance(hp["speed_perturb"], sb.SpeedPerturb) and hp["speed_perturb"].speeds == [95, 100, 105]
