@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: ConMamba-large CTC encoder forward, audio-frames/sec (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1: starts its own N ranks, one per GPU, as a child
+                                                             `python -m torch.distributed.run`, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --mode train [--gpus N]                 data-parallel TRAINING step (fwd + bwd + AdamW, grad-accum 4,
+                                                             gradient all-reduce over RCCL): secondary figure
 
 A step = one pass of the hot path over one synthetic batch that is already resident in HBM:
 wav (B x 40 s @ 16 kHz) -> Fbank -> global normalisation -> CNN front end -> src Linear -> 18 ConMamba
@@ -16,10 +19,10 @@ sample, rank 0 at N=1 only.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -47,7 +50,32 @@ def parse():
                     help="join (default): the scan runs once per layer on the whole batch; free: fully independent parts")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=64, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward (default, the headline metric) or train: fwd + bwd + AdamW through the Brain loop with the "
+                         "gradient exchange of mamba_asr_amd.ddp (reference train_CTC.py:1062 + conmamba_large.yaml:90)")
+    ap.add_argument("--lens", choices=["full", "uniform"], default="full",
+                    help="utterance lengths: full (wav_lens = 1, the roofline run) or uniform (relative lengths ~U(0.5, 1), "
+                         "zero padded to --frames: SURVEY §8d's ragged run)")
+    ap.add_argument("--accum", type=int, default=4, help="train mode: grad_accumulation_factor (conmamba_large.yaml:90)")
+    ap.add_argument("--comm-dtype", choices=["f32", "bf16"], default="f32", help="train mode: gradient transport dtype")
+    ap.add_argument("--ddp-algo", choices=["allreduce", "mesh"], default=None, help="train mode: see mamba_asr_amd/ddp.py")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as a CHILD
+    `python -m torch.distributed.run` and return its exit code.  Runs before anything touches the GPU in this process
+    (a process that has initialised the GPU must not be replaced; a child process is fine)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(model, cfg, frames, batch):
@@ -80,16 +108,155 @@ def cpu_baseline(model, cfg, frames, batch):
                       f"frontend+encoder forward, fp32, {scan_kind}, {dt:.1f} s wall"}
 
 
+def pmc_traffic(batch, seqlen, dim, dtype):
+    """HBM bytes of one scan launch from the PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
+    runs of tools/pmc_scan.py, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; summaries committed under
+    profiles/rNN/): newest round first; valid only for the configuration it was measured on, else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_scan_rows.json")), reverse=True):
+        try:
+            with open(path) as f:
+                for run in json.load(f)["runs"]:
+                    w = run["workload"]
+                    if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (batch, seqlen, dim, dtype):
+                        return run["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def make_batch(a, cfg, rank, dev):
+    """Synthetic 16 kHz utterances resident in HBM: full length, or relative lengths ~U(0.5, 1) with the
+    tail zero padded (what the reference's padded batches look like; ConMamba applies no padding mask, Conmamba.py:635)."""
+    from mamba_asr_amd.asr import samples_for_frames, synthetic_wavs
+    wavs, lens = synthetic_wavs(a.batch, samples_for_frames(a.frames), cfg.seed + rank, dev)
+    if a.lens == "uniform":
+        g = torch.Generator().manual_seed(cfg.seed + 1000 + rank)
+        rel = 0.5 + 0.5 * torch.rand(a.batch, generator=g)
+        rel[0] = 1.0                                           # a padded batch always holds one full-length utterance
+        n = wavs.shape[1]
+        keep = torch.arange(n)[None, :] < torch.round(rel * n)[:, None]
+        wavs = wavs * keep.to(dev)
+        lens = rel.to(dev)
+    return wavs, lens
+
+
+def run_train(a, cfg, dev, rank, world, use_dist):
+    """Data-parallel training step (BASELINE.json config 4; reference train_CTC.py fit_batch through speechbrain's Brain +
+    DDP, hparams/CTC/conmamba_large.yaml:84-91, 243-252): bf16 autocast, SpecAugment, CTC loss, backward, and every
+    ``--accum``-th micro-batch the gradient exchange (mamba_asr_amd.ddp over RCCL), clip 5.0, AdamW, Noam.
+    A step here = one micro-batch; `value` = audio frames all ranks push through fwd + bwd per second."""
+    import torch.distributed as dist
+    from mamba_asr_amd import ops
+    from mamba_asr_amd import sb_compat as sb
+    from mamba_asr_amd.asr import ConMambaASR
+    from mamba_asr_amd.brain import Brain, Stage
+    from mamba_asr_amd.ddp import GradAllReducer
+    model = ConMambaASR(cfg).to(dev)
+    aug = sb.Augmenter(augmentations=[sb.SpectrogramDrop(6, 12, 1, 5, "mean", 1), sb.SpectrogramDrop(10, 20, 1, 3, "mean", 2)])
+
+    class ASR(Brain):
+        def compute_forward(self, batch, stage):
+            wavs, lens, tokens, tlens = batch
+            return self.modules["asr"].forward_ctc(wavs, lens, epoch=0, augment=aug if stage == Stage.TRAIN else None)
+
+        def compute_objectives(self, p_ctc, batch, stage):
+            wavs, lens, tokens, tlens = batch
+            return self.modules["asr"].ctc_objective(p_ctc, tokens, lens, tlens)
+
+        def on_fit_batch_end(self, batch, outputs, loss, should_step):
+            if should_step:
+                self.hparams.noam(self.optimizer)
+
+    brain = ASR({"asr": model}, opt_class=lambda ps: torch.optim.AdamW(ps, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=5e-4),
+                hparams={"precision": "bf16" if a.dtype == "bf16" else "fp32", "grad_accumulation_factor": a.accum,
+                         "max_grad_norm": 5.0, "noam": sb.NoamScheduler(1e-3, 7500)}, run_opts={"device": str(dev)})
+    params = [p for p in brain.modules.parameters() if p.requires_grad]
+    if use_dist:                                               # also at world 1: the exchange then runs through RCCL alone
+        brain.reducer = GradAllReducer(params, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None, algo=a.ddp_algo,
+                                       always_exchange=True)
+    brain.on_fit_start()
+    brain.modules.train()
+    wavs, lens = make_batch(a, cfg, rank, dev)
+    g = torch.Generator().manual_seed(rank)
+    tokens = torch.randint(3, cfg.output_neurons, (a.batch, a.frames // 8), generator=g).to(dev)     # ~12.5 chars/s
+    batch = (wavs, lens, tokens, lens.clone())
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    losses = [brain.fit_batch(batch) for _ in range(max(a.warmup, 1))]
+    fence()
+    t0 = time.perf_counter()
+    exposed = []
+    for _ in range(a.steps):
+        losses.append(brain.fit_batch(batch))
+        if brain.reducer is not None and brain.step % a.accum == 0:
+            exposed.append(brain.reducer.exposed_s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = [float(l) for l in losses]
+    assert all(l == l for l in losses), "non-finite loss"
+    value = world * a.batch * a.frames * a.steps / elapsed
+    roof = None
+    # backward-scan roofline: one more micro-batch on EVERY rank (it may end in the exchange), HIP events on rank 0
+    ops.LAUNCH_LOG = [] if rank == 0 else None
+    brain.fit_batch(batch)
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    if rank == 0:
+        ts = [e0.elapsed_time(e1) for name, e0, e1, _ in log if name == "cm_selective_scan_bwd"]
+        if ts:
+            e_inner, n_state, s_ = cfg.expand * cfg.d_model, cfg.d_state, (2 if a.dtype == "bf16" else 4)
+            units = a.batch * (a.frames // 4)                                       # scan steps per launch (one direction)
+            alg = units * (9 * e_inner + 4 * n_state) * s_                          # SURVEY §8d: fwd reads + dout, du/ddelta/dz + dB/dC
+            avg_ms = sum(ts) / len(ts)
+            roof = {"bound": "hbm", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "scan_bwd_kernel (cm_selective_scan_bwd, one direction per launch)",
+                    "avg_launch_us": round(avg_ms * 1e3, 1), "launches_per_step": len(ts), "alg_bytes_per_launch": alg}
+    if rank == 0:
+        line = {"metric": f"training audio-frames/sec ({cfg.name}, L={a.frames}, fwd+bwd+AdamW)", "value": round(value, 1),
+                "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": a.dtype, "data": "synthetic",
+                "config": {"workload": f"{cfg.name}: CTC training micro-batch, {a.batch} utterances x {a.frames} frames per GPU, "
+                                       f"SpecAugment, grad_accumulation_factor {a.accum}, AdamW + Noam, clip 5.0",
+                           "global_batch": world * a.batch, "frames_per_utterance": a.frames,
+                           "parallelism": f"dp{world}: gradient exchange every {a.accum} micro-batches "
+                                          f"({'RCCL ' + (brain.reducer.algo if brain.reducer else '') if use_dist else 'none: single process'})"},
+                "allreduce_bytes_per_optimizer_step": brain.reducer.bytes_per_step() if brain.reducer else 0,
+                "exposed_comm_ms_per_optimizer_step": round(1e3 * sum(exposed) / len(exposed), 3) if exposed else None,
+                "optimizer_steps": brain.optimizer_step, "loss_first_last": [round(losses[0], 3), round(losses[-1], 3)],
+                "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "roofline": roof, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     a = parse()
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # started by torch.distributed.run
+    if not launched and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {a.gpus} "
+                         f"(or run `python bench.py --gpus {a.gpus}` without a launcher and it starts the ranks itself)")
+    global torch
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    use_dist = launched
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
@@ -102,15 +269,21 @@ def main():
     if a.stream_mode is not None:
         fused.STREAM_MODE = a.stream_mode
     cfg = CONFIGS[a.config]
+    if a.mode == "train":
+        run_train(a, cfg, dev, rank, world, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     model = ConMambaASR(cfg).to(dev).eval()
-    wavs, lens = synthetic_wavs(a.batch, samples_for_frames(a.frames), cfg.seed + rank, dev)
+    wavs, lens = make_batch(a, cfg, rank, dev)
     amp = torch.bfloat16 if a.dtype == "bf16" else None
 
     def eager_step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp is not None):
             return model.encode(wavs, lens)
 
-    eager_step()                                            # first batch: fills the global normalisation statistics
+    model.calibrate(wavs, lens)                             # first batch: fills the global normalisation statistics
+    eager_step()
     if a.no_graph:
         step = eager_step
     else:
@@ -157,17 +330,7 @@ def main():
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             # HBM traffic of one launch from the PMC passes (FETCH_SIZE, WRITE_SIZE collected separately with rocprofv3
             # --pmc on tools/pmc_scan.py, profiles/): valid for the configuration it was measured on only
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01", "pmc_scan_rows.json")) as f:
-                    pmc = json.load(f)
-                for run in pmc["runs"]:
-                    w = run["workload"]
-                    if (w["batch"], w["seqlen"], w["dim"], w["dtype"]) == (units // (2 * (a.frames // 4)), a.frames // 4, e_inner,
-                                                                              "bf16" if amp is not None else "f32"):
-                        traffic = run["traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                pass
+            traffic = pmc_traffic(units // (2 * (a.frames // 4)), a.frames // 4, e_inner, "bf16" if amp is not None else "f32")
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": "scan_rows_fwd_kernel (cm_scan_cl_fwd, xdbl mode: both BiMamba directions per launch)", "avg_launch_us": round(avg_ms * 1e3, 1),
@@ -188,7 +351,8 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
             "config": {"workload": f"{a.config}: encoder forward, {a.batch} utterances x {a.frames} frames "
-                                   f"({a.frames // 4} scan steps) per GPU, random-init weights",
+                                   f"({a.frames // 4} scan steps) per GPU, random-init weights"
+                                   + ("" if a.lens == "full" else ", relative lengths ~U(0.5, 1) zero padded"),
                        "global_batch": world * a.batch, "frames_per_utterance": a.frames,
                        "parallelism": f"utterance shards x{world} (no collective in forward)",
                        "launch": "eager" if a.no_graph else "hipGraph replay",

@@ -71,6 +71,8 @@ class ConMambaASR(nn.Module):
         self.ctc_lin = sb.Linear(input_size=cfg.d_model, n_neurons=cfg.output_neurons)
         if cfg.num_decoder_layers > 0:
             self.seq_lin = sb.Linear(input_size=cfg.d_model, n_neurons=cfg.output_neurons)
+        from . import ops
+        self.register_load_state_dict_post_hook(lambda module, incompatible: ops.invalidate_caches(module))
 
     # -- train_CTC.py:285-298 -------------------------------------------------------------
     def features(self, wavs, wav_lens, epoch=0, augment=None):
@@ -79,6 +81,12 @@ class ConMambaASR(nn.Module):
         if augment is not None and self.training:
             feats, _ = augment(feats, wav_lens)
         return feats
+
+    @torch.no_grad()
+    def calibrate(self, wavs, wav_lens):
+        """Fill the global normalisation statistics from one batch outside training (the reference gets them from its
+        first training batches, train_CTC.py:287; benchmarks / parity runs on random-init models call this once)."""
+        self.normalize.update_statistics(self.compute_features(wavs), wav_lens)
 
     def encode(self, wavs, wav_lens, epoch=0, augment=None):
         """wav (B, samples) -> encoder output (B, ceil(T/4), d_model): the path the headline metric times."""

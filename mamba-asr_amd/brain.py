@@ -95,12 +95,17 @@ class Brain:
         if should_step:
             if self.reducer is not None:
                 self.reducer.finish()
-            params = [p for p in self.modules.parameters() if p.grad is not None]
-            norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                norm = self.reducer.clip_grad_norm_(self.max_grad_norm)       # on the flat gradient buckets
+            else:
+                params = [p for p in self.modules.parameters() if p.grad is not None]
+                norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
             if torch.isfinite(norm) and torch.isfinite(loss):
                 self.optimizer.step()
                 self.optimizer_step += 1
-            self.optimizer.zero_grad(set_to_none=True)
+            if self.reducer is not None:
+                self.reducer.zero_grad()                 # memset of the buckets; the .grad views stay attached
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
         self.step += 1
         self.on_fit_batch_end(batch, outputs, loss, should_step)
         return loss.detach()

@@ -88,12 +88,22 @@ class DurationBucketBatchSampler:
             batches.sort(key=lambda bt: max(self.durations[i] for i in bt), reverse=self.ordering == "descending")
         return batches
 
+    def _shard(self) -> List[List[int]]:
+        # data parallel: rank r takes batches r, r + world, ... of the common list (every rank builds the same list).
+        # Every rank must see the SAME number of batches -- each stepping micro-batch ends in a collective, and a rank
+        # with one batch more would wait for peers that never arrive -- so the list is padded to a multiple of the world
+        # size by repeating its leading batches (what torch's DistributedSampler does with drop_last=False).
+        batches = self._batches
+        if self.world > 1 and batches and len(batches) % self.world:
+            pad = self.world - len(batches) % self.world
+            batches = batches + [batches[i % len(batches)] for i in range(pad)]
+        return batches[self.rank::self.world]
+
     def __iter__(self) -> Iterator[List[int]]:
-        # data parallel: rank r takes batches r, r + world, ... of the common list (every rank builds the same list)
-        return iter(self._batches[self.rank::self.world])
+        return iter(self._shard())
 
     def __len__(self) -> int:
-        return len(self._batches[self.rank::self.world])
+        return len(self._shard())
 
 
 def ctc_greedy_decode(log_probs: torch.Tensor, wav_lens: torch.Tensor, blank_id: int = 0) -> List[List[int]]:

@@ -97,7 +97,8 @@ class _LayerCache:
 
     @staticmethod
     def _ver(layer):
-        return sum(p._version for p in layer.parameters())
+        # (version, storage) per parameter: see ops.cast_cached / ops.invalidate_caches
+        return hash(tuple((p._version, p.data_ptr()) for p in layer.parameters()))
 
     def stale(self, layer, dtype):
         return dtype != self.dtype or self._ver(layer) != self.version
@@ -442,7 +443,7 @@ USE_CNN_FRONT = os.environ.get("CM_CNN_FRONT", "1") == "1"
 
 def _frontend_cache(model, dtype):
     c = getattr(model, "_cm_frontend_cache", None)
-    ver = sum(p._version for p in model.CNN.parameters()) + sum(p._version for p in model.Transformer.custom_src_module.parameters())
+    ver = hash(tuple((p._version, p.data_ptr()) for m in (model.CNN, model.Transformer.custom_src_module) for p in m.parameters()))
     if c is None or c["dtype"] != dtype or c["ver"] != ver:
         b0, b1 = model.CNN.blocks
         lin = model.Transformer.custom_src_module.layers[0].w

@@ -24,6 +24,7 @@ _SB_MAP = {
     "speechbrain.processing.features.InputNormalization": "mamba_asr_amd.sb_compat.InputNormalization",
     "speechbrain.lobes.features.Fbank": "mamba_asr_amd.sb_compat.Fbank",
     "speechbrain.augment.freq_domain.SpectrogramDrop": "mamba_asr_amd.sb_compat.SpectrogramDrop",
+    "speechbrain.augment.freq_domain.Warping": "mamba_asr_amd.sb_compat.Warping",
     "speechbrain.augment.augmenter.Augmenter": "mamba_asr_amd.sb_compat.Augmenter",
     "speechbrain.augment.time_domain.SpeedPerturb": "mamba_asr_amd.sb_compat.SpeedPerturb",
     "speechbrain.nnet.losses.kldiv_loss": "mamba_asr_amd.sb_compat.kldiv_loss",

@@ -72,6 +72,12 @@ class TransformerASR(nn.Module):
                  gate_activation=nn.Identity, use_linear_after_conv=False, mamba_config=None):
         super().__init__()
         assert num_encoder_layers + num_decoder_layers > 0
+        if attention_type != "RelPosMHAXL":
+            # every ConMamba recipe sets RelPosMHAXL (hparams/CTC/conmamba_large.yaml:164), whose branch adds no
+            # positional encoding to src (reference :777-778 computes RelPosEncXL and ConMamba discards it); the
+            # fixed_abs_sine branch (reference :779-781, 797-800) would add one and is not built: fail loudly
+            raise NotImplementedError(f"attention_type={attention_type!r}: only 'RelPosMHAXL' (the ConMamba recipes' setting) "
+                                      "is implemented; other types add sinusoidal positions to src in the reference")
         self.causal, self.attention_type, self.positional_encoding_type = causal, attention_type, positional_encoding
         self.num_decoder_layers = num_decoder_layers
         if encoder_module != "conmamba":

@@ -43,14 +43,33 @@ def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if p.dtype == dtype:
         return p.detach()
     c = getattr(p, "_cm_cast", None)
-    if c is not None and c[0] == p._version and c[1].dtype == dtype and c[1].device == p.device:
+    key = (p._version, p.data_ptr())             # data_ptr: `p.data = ...` swaps storage without bumping _version
+    if c is not None and c[0] == key and c[1].dtype == dtype and c[1].device == p.device:
         return c[1]
     t = p.detach().to(dtype)
     try:
-        p._cm_cast = (p._version, t)
+        p._cm_cast = (key, t)
     except (AttributeError, RuntimeError):
         pass
     return t
+
+
+def invalidate_caches(module: torch.nn.Module) -> None:
+    """Drop every cached low-precision weight copy under ``module`` (cast_cached's per-parameter copies and the fused
+    path's per-layer images).  The caches key on (parameter version, storage pointer): in-place writes made under
+    torch.no_grad() on the parameter itself, optimizer steps, load_state_dict and `p.data = new` are seen; writes
+    THROUGH ``p.data`` (``p.data.copy_()``, EMA / SWA code, vector_to_parameters) are not -- call this after them.
+    load_state_dict calls it by itself (hook installed by asr.ConMambaASR)."""
+    for p in module.parameters():
+        if hasattr(p, "_cm_cast"):
+            try:
+                del p._cm_cast
+            except AttributeError:
+                pass
+    for m in module.modules():
+        for attr in ("_cm_fused_cache", "_cm_frontend_cache"):
+            if hasattr(m, attr):
+                delattr(m, attr)
 
 
 def _ptr(t: Optional[torch.Tensor]):

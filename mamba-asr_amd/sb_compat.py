@@ -213,7 +213,13 @@ class Fbank(nn.Module):
 
 class InputNormalization(nn.Module):
     """speechbrain.processing.features.InputNormalization(norm_type='global', update_until_epoch):
-    running average (weight 1/(count+1)) of per-utterance mean/std over valid frames."""
+    running average (weight 1/(count+1)) of per-utterance mean/std over valid frames.
+
+    As in speechbrain the statistics move only in training mode (first batch, then while epoch < update_until_epoch);
+    in eval they are frozen, and before any update they are mean 0 / std 1.  ``count`` travels with glob_mean /
+    glob_std in the state_dict (speechbrain checkpoints it alongside them), and the buffers take the checkpoint's
+    shape on load, so a trained model restores into a fresh one.  ``update_statistics`` is the explicit way to fill them
+    from a batch outside training (benchmarks and tests calibrate on their first batch with it)."""
 
     def __init__(self, mean_norm=True, std_norm=True, norm_type="global", avg_factor=None, requires_grad=False,
                  update_until_epoch=3):
@@ -223,24 +229,47 @@ class InputNormalization(nn.Module):
         self.update_until_epoch = update_until_epoch
         self.register_buffer("glob_mean", torch.zeros(1))
         self.register_buffer("glob_std", torch.ones(1))
+        self.register_buffer("count_buf", torch.zeros((), dtype=torch.long))
         self.count = 0
         self.eps = 1e-10
 
+    # ``count`` stays a host integer (no device sync per batch); the buffer mirrors it for the state_dict
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.count_buf.fill_(self.count)
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in ("glob_mean", "glob_std"):                   # (1,) placeholders become (n_mels,) after the first batch
+            t = state_dict.get(prefix + name)
+            if t is not None and t.shape != getattr(self, name).shape:
+                setattr(self, name, torch.empty_like(t, device=getattr(self, name).device))
+        if prefix + "count_buf" not in state_dict and prefix + "glob_mean" in state_dict:
+            # checkpoint written before count was saved: statistics present -> treat as calibrated
+            state_dict = dict(state_dict)
+            state_dict[prefix + "count_buf"] = torch.tensor(int(state_dict[prefix + "glob_mean"].numel() > 1))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self.count = int(self.count_buf)
+
+    @torch.no_grad()
+    def update_statistics(self, x, lengths):
+        """One running-average update from batch ``x`` (batch, frames, feats) with relative ``lengths``."""
+        n = torch.round(lengths * x.shape[1]).long().clamp(min=1)
+        mask = (torch.arange(x.shape[1], device=x.device)[None, :] < n[:, None]).to(x.dtype)[..., None]
+        cnt = n.to(x.dtype)[:, None]
+        mean = (x * mask).sum(1) / cnt
+        var = (((x - mean[:, None]) * mask) ** 2).sum(1) / (cnt - 1).clamp(min=1)
+        cur_mean, cur_std = mean.mean(0), var.sqrt().clamp(min=self.eps).mean(0)
+        w = 1.0 / (self.count + 1) if self.avg_factor is None else self.avg_factor
+        if self.count == 0:
+            self.glob_mean, self.glob_std = cur_mean.detach(), cur_std.detach()
+        else:
+            self.glob_mean = ((1 - w) * self.glob_mean + w * cur_mean).detach()
+            self.glob_std = ((1 - w) * self.glob_std + w * cur_std).detach()
+        self.count += 1
+
     def forward(self, x, lengths, spk_ids=None, epoch=0):
-        if self.training and epoch < self.update_until_epoch or self.count == 0:
-            n = torch.round(lengths * x.shape[1]).long().clamp(min=1)
-            mask = (torch.arange(x.shape[1], device=x.device)[None, :] < n[:, None]).to(x.dtype)[..., None]
-            cnt = n.to(x.dtype)[:, None]
-            mean = (x * mask).sum(1) / cnt
-            var = (((x - mean[:, None]) * mask) ** 2).sum(1) / (cnt - 1).clamp(min=1)
-            cur_mean, cur_std = mean.mean(0), var.sqrt().clamp(min=self.eps).mean(0)
-            w = 1.0 / (self.count + 1) if self.avg_factor is None else self.avg_factor
-            if self.count == 0:
-                self.glob_mean, self.glob_std = cur_mean.detach(), cur_std.detach()
-            else:
-                self.glob_mean = ((1 - w) * self.glob_mean + w * cur_mean).detach()
-                self.glob_std = ((1 - w) * self.glob_std + w * cur_std).detach()
-            self.count += 1
+        if self.training and (self.count == 0 or epoch < self.update_until_epoch):
+            self.update_statistics(x, lengths)
         return (x - self.glob_mean) / self.glob_std
 
 
@@ -268,6 +297,42 @@ class SpectrogramDrop(nn.Module):
             from . import ops
             return ops.spec_drop_(spec.contiguous().clone(), start, length, self.dim, val)
         return torch.where(mask, val.to(spec.dtype), spec)
+
+
+class Warping(nn.Module):
+    """speechbrain.augment.freq_domain.Warping(warp_window=5, warp_mode='bicubic', dim=1) -- the S2S recipes' time warp
+    (reference hparams/S2S/conmambamamba_large.yaml:471-491): one random centre c in [window, T - window) and target
+    w in (c - window, c + window] per batch; the part before c is resized to w steps and the part from c on to T - w steps
+    (interpolation with align_corners=True along the warped axis only; the other axis keeps its size), so the spectrogram
+    keeps its shape.  Tensors shorter than 2 * window + 1 pass through.  (speechbrain absent: restated, parity unpinned;
+    tests/test_warping.py pins shape, the untouched cases and the closed form on a ramp.)"""
+
+    def __init__(self, warp_window=5, warp_mode="bicubic", dim=1):
+        super().__init__()
+        self.warp_window, self.warp_mode, self.dim = warp_window, warp_mode, dim
+
+    def forward(self, spectrogram):
+        x = spectrogram.transpose(1, 2) if self.dim == 2 else spectrogram
+        squeeze = x.dim() == 3
+        if squeeze:
+            x = x.unsqueeze(1)                                   # (batch, 1, T, F): 2-d interpolation wants 4-d
+        T, window = x.shape[2], self.warp_window
+        if T - window <= window:
+            return spectrogram
+        c = int(torch.randint(window, T - window, (1,)))
+        w = int(torch.randint(c - window, c + window, (1,))) + 1
+        out = self.warp(x, c, w)
+        if squeeze:
+            out = out.squeeze(1)
+        return out.transpose(1, 2) if self.dim == 2 else out
+
+    def warp(self, x, c: int, w: int):
+        """x (batch, ch, T, F): [0, c) -> w steps, [c, T) -> T - w steps."""
+        T, Fq = x.shape[2], x.shape[3]
+        kw = dict(mode=self.warp_mode, align_corners=True) if self.warp_mode in ("bilinear", "bicubic") else dict(mode=self.warp_mode)
+        left = F.interpolate(x[:, :, :c], (w, Fq), **kw)
+        right = F.interpolate(x[:, :, c:], (T - w, Fq), **kw)
+        return torch.cat([left, right], dim=2)
 
 
 class Augmenter(nn.Module):

@@ -405,6 +405,38 @@ def decoder_layer(p, tgt, memory, prefix="", scan=selective_scan):
     return tgt + F.linear(h, g("pos_ffn.ffn.3.weight"), g("pos_ffn.ffn.3.bias"))     # :946-949
 
 
+def decoder(p, tgt, memory, num_layers, prefix="", scan=selective_scan):
+    """MambaDecoder.forward, Conmamba.py:1017-1031: the layers, then the final LayerNorm (eps 1e-6)."""
+    for i in range(num_layers):
+        tgt = decoder_layer(p, tgt, memory, f"{prefix}layers.{i}.", scan)
+    return _ln(tgt, p[prefix + "norm.norm.weight"].to(tgt.dtype), p[prefix + "norm.norm.bias"].to(tgt.dtype), 1e-6)
+
+
+def mamba_step(p, hidden, conv_state, ssm_state, prefix=""):
+    """One decoding step, restating the pure-torch fallback of reference modules/mamba/bimamba.py:320-365.
+    hidden (b, 1, d); conv_state (b, e, w) and ssm_state (b, e, n) are updated in place.  -> out (b, 1, d)."""
+    g = lambda k: p[prefix + k]
+    rank, n = g("dt_proj.weight").shape[1], g("A_log").shape[1]
+    xz = F.linear(hidden[:, 0], g("in_proj.weight"))                                # :323
+    e = xz.shape[-1] // 2
+    x, z = xz[:, :e], xz[:, e:]                                                     # :324
+    conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))                    # :328
+    conv_state[:, :, -1] = x                                                        # :329
+    x = (conv_state * g("conv1d.weight").reshape(e, -1)).sum(-1) + g("conv1d.bias")  # :330-332
+    x = F.silu(x)                                                                   # :333
+    x_db = F.linear(x, g("x_proj.weight"))                                          # :343
+    dt, Bm, Cm = x_db[:, :rank], x_db[:, rank:rank + n], x_db[:, rank + n:]         # :344
+    dt = F.linear(dt, g("dt_proj.weight"))                                          # :346 (no bias here)
+    A = -torch.exp(g("A_log").float())                                              # :347
+    dt = F.softplus(dt + g("dt_proj.bias"))                                         # :352
+    dA = torch.exp(dt[:, :, None] * A[None])                                        # :353
+    dB = dt[:, :, None] * Bm[:, None, :]                                            # :354
+    ssm_state.copy_(ssm_state * dA + x[:, :, None] * dB)                            # :355
+    y = (ssm_state * Cm[:, None, :]).sum(-1) + g("D") * x                           # :356-357
+    y = y * F.silu(z)                                                               # :358
+    return F.linear(y, g("out_proj.weight"))[:, None]                               # :364-365
+
+
 # --------------------------------------------------------------------------
 # a15. frontend (speechbrain 1.0.0 semantics restated; PARITY UNPINNED — see header)
 # --------------------------------------------------------------------------

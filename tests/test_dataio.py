@@ -33,8 +33,15 @@ def test_bucket_sampler_invariants_and_sharding():
     longest = [max(dur[i] for i in b) for b in asc]
     assert longest == sorted(longest)
     shards = [dataio.DurationBucketBatchSampler(dur, 850, seed=3, rank=r, world=4) for r in range(4)]
-    union = sorted(i for sh in shards for b in sh for i in b)
-    assert union == list(range(2000)) and abs(len(shards[0]) - len(shards[3])) <= 1
+    union = sorted(set(i for sh in shards for b in sh for i in b))
+    assert union == list(range(2000))
+    # every rank yields the SAME number of batches (each stepping micro-batch ends in a collective): the common list is
+    # padded with its leading batches when it does not divide by the world size
+    assert len({len(sh) for sh in shards}) == 1 and len({len(list(sh)) for sh in shards}) == 1
+    for world in (2, 3, 4, 7):
+        sh = [dataio.DurationBucketBatchSampler(dur[:331], 850, seed=1, rank=r, world=world) for r in range(world)]
+        assert len({len(list(x)) for x in sh}) == 1
+        assert sorted(set(i for x in sh for b in x for i in b)) == list(range(331))
 
 
 def test_ctc_greedy_decode_collapses_and_drops_blanks():

@@ -70,6 +70,41 @@ def _worker(rank, world, port, q):
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     ok = ok and brain.optimizer_step == 2 and torch.allclose(gathered[0], gathered[1], atol=1e-6)
+    # gradients live in the persistent buckets across steps: .grad is still the bucket view after zero_grad
+    red2 = brain.reducer
+    ok = ok and all(p.grad is not None and p.grad.data_ptr() == red2._view[p].data_ptr() for p in red2.params)
+    ok = ok and all(float(b.flat.abs().max()) == 0.0 for b in red2.buckets)
+
+    # the mesh algorithm (all-to-all + fixed-order sum + all-gather) and bf16 transport give the same means
+    for algo, cdt, tol in (("mesh", None, 1e-6), ("allreduce", torch.bfloat16, 2e-2), ("mesh", torch.bfloat16, 2e-2)):
+        m = _model()
+        try:
+            r2 = GradAllReducer(m.parameters(), bucket_mb=0.004, algo=algo, comm_dtype=cdt)
+            (2 * ((m(x) - y) ** 2).mean()).backward()
+            r2.finish()
+        except RuntimeError as e:                   # gloo builds without all_to_all: the algebra is still checked below
+            if "all_to_all" in str(e) or "alltoall" in str(e).lower():
+                continue
+            raise
+        ok = ok and all(torch.allclose(p.grad, (a + b) / 2, atol=tol, rtol=tol) for p, a, b in zip(m.parameters(), *both))
+
+    # Brain.fit through the duration-bucket sampler with an ODD number of batches: every rank must run the same number of
+    # micro-batches or the last all-reduce has no peer
+    from mamba_asr_amd.dataio import DurationBucketBatchSampler
+    dur = [1.0 + 0.1 * i for i in range(33)]
+    smp = DurationBucketBatchSampler(dur, max_batch_length=30.0, num_buckets=4, seed=5, rank=rank, world=world)
+    n_common = len(DurationBucketBatchSampler(dur, max_batch_length=30.0, num_buckets=4, seed=5))
+    gd = torch.Generator().manual_seed(9)
+    pool = [(torch.randn(16, generator=gd), torch.randn(5, generator=gd)) for _ in dur]
+    batches = [(torch.stack([pool[i][0] for i in b]), torch.stack([pool[i][1] for i in b])) for b in smp]
+    brain2 = B({"net": _model()}, opt_class=lambda ps: torch.optim.SGD(ps, lr=0.05),
+               hparams={"grad_accumulation_factor": 1}, run_opts={"device": "cpu"})
+    brain2.fit(range(1), batches)
+    flat = torch.cat([p.detach().reshape(-1) for p in brain2.modules.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = ok and n_common % world == 1 and brain2.optimizer_step == (n_common + 1) // world
+    ok = ok and torch.allclose(gathered[0], gathered[1], atol=1e-6)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

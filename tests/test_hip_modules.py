@@ -186,7 +186,8 @@ def test_fused_frontend_and_encoder_match_unfused_and_oracle(dtype):
     model = ConMambaASR(cfg).to(DEV).eval()
     wavs, lens = synthetic_wavs(2, samples_for_frames(203), 9, DEV)
     with torch.no_grad():
-        feats = model.features(wavs, lens)                                  # fills the normaliser statistics
+        model.calibrate(wavs, lens)                                         # fills the normaliser statistics
+        feats = model.features(wavs, lens)
         ref = model.Transformer.encode(model.CNN(feats), lens)               # module path (fp32)
         got = fused.asr_encode(model, wavs, lens, dtype=dtype)
     assert got.shape == ref.shape == (2, 51, 64)
@@ -429,7 +430,7 @@ def test_ctc_loss_matches_oracle_within_1e3():
     tokens = torch.randint(3, 31, (3, 20), generator=gen)
     tok_lens = torch.tensor([1.0, 0.8, 0.6])
     with torch.no_grad():
-        model.features(wavs, lens)                                         # normaliser statistics from the first batch
+        model.calibrate(wavs, lens)                                        # normaliser statistics from the first batch
         p32 = model.forward_ctc(wavs, lens)
         loss32 = model.ctc_objective(p32, tokens.to(DEV), lens, tok_lens.to(DEV))
         with torch.autocast("cuda", dtype=torch.bfloat16):

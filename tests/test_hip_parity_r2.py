@@ -1,0 +1,297 @@
+"""GPU parity, round 2: the kernels the benchmark times and the BASELINE.json configurations, against vectors the
+REFERENCE produced (tests/golden/make_golden_r2.py) or, at sizes a fixture cannot hold, against the CPU oracle
+(itself pinned to the same vectors by tests/test_oracle_golden.py).
+
+  * ConMamba-large dims end to end through the fused kernels (cm_ffn_fused, cm_conv_xproj, cm_ln_pw_glu, the
+    row-group cm_scan_cl_fwd, joined multi-stream route) vs the reference's 2-layer encoder          [config 3]
+  * BiMamba v2 at d_model 256: forward + every gradient vs the reference                              [a7]
+  * mamba_inner_fn WITH out_proj: forward + every gradient vs the reference's mamba_inner_ref         [a4]
+  * bimamba_inner_fn (v1) and the *_ref compositions vs the reference's bimamba_inner_ref             [a5, a6]
+  * MambaDecoderLayer gradients, 2-layer MambaDecoder incl. final norm vs the reference               [a13]
+  * single-step decode vs the reference's own pure-torch step fallback                                [f2]
+  * ConMamba-small CTC end to end (D 144, 12 layers, n_fft 400, 4 x 10 s) vs the oracle, CTC |delta|  [configs 1, 2]
+  * S2S-large dims (D 512, E 1024, R 32): 2 encoder + 1 decoder layer vs the oracle                   [config 5]
+  * ConMamba-large CTC (18 layers) loss vs the oracle; ragged wav_lens at T = 1000                    [north star]
+
+Tolerances: fp32 module level rtol 2e-3 / atol 2e-4 x max|ref|; bf16 encoder output rtol 3e-2 /
+atol 5e-2; CTC loss |delta| <= 1e-3 in fp32 (BASELINE.json north_star).
+"""
+import importlib.util
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CFG = {"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True}
+
+_spec = importlib.util.spec_from_file_location("golden_synth", os.path.join(os.path.dirname(__file__), "golden", "synth.py"))
+S = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(S)
+
+
+def close(a, b, rtol=2e-3, atol=2e-4):
+    scale = max(1.0, float(b.abs().max()))
+    torch.testing.assert_close(a.detach().double().cpu(), b.detach().double().cpu(), rtol=rtol, atol=atol * scale)
+
+
+def _params(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def _launched(fn):
+    """Run fn() with every native launch logged; -> (result, set of C-ABI entry names that ran)."""
+    from mamba_asr_amd import ops
+    ops.LAUNCH_LOG = []
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        names = {e[0] for e in ops.LAUNCH_LOG}
+    finally:
+        ops.LAUNCH_LOG = None
+    return out, names
+
+
+# ----------------------------------------------------------------------------------------------------------
+# config 3: the benchmarked kernels, end to end, against the reference
+# ----------------------------------------------------------------------------------------------------------
+def _large_encoder():
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    enc = ConmambaEncoder(num_layers=2, d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True, dropout=0.0,
+                          causal=False, mamba_config=dict(CFG))
+    enc.load_state_dict(S.synth_like(enc, 256), strict=True)
+    return enc.to(DEV).eval(), S.synth_input("g4_large.x", (16, 100, 256), 256).to(DEV)
+
+
+def test_large_encoder_fp32_vs_reference(golden):
+    from mamba_asr_amd import fused
+    g = golden("g4_large")
+    enc, x = _large_encoder()
+    with torch.no_grad():
+        close(enc.layers[0](x), g["y_layer0"])                        # module API (operator kernels)
+        close(fused.encoder_forward(enc, x, dtype=torch.float32, streams=1), g["y_enc"])
+        close(fused.encoder_forward(enc, x, dtype=torch.float32, streams=2), g["y_enc"])
+
+
+@pytest.mark.parametrize("streams,mode", [(1, "join"), (2, "join"), (2, "free")])
+def test_large_encoder_bf16_benchmark_kernels_vs_reference(golden, monkeypatch, streams, mode):
+    """bf16, d_model 256: this is the route bench.py times.  Asserts that the fused kernels are the ones that ran."""
+    from mamba_asr_amd import fused
+    g = golden("g4_large")
+    enc, x = _large_encoder()
+    monkeypatch.setattr(fused, "STREAM_MODE", mode)
+    with torch.no_grad():
+        out, names = _launched(lambda: fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=streams))
+    for k in ("cm_ffn_fused", "cm_conv_xproj", "cm_ln_pw_glu", "cm_scan_cl_fwd", "cm_glu_dwconv_ln_gelu"):
+        assert k in names, f"{k} did not run (ran: {sorted(names)})"
+    torch.testing.assert_close(out.float().cpu(), g["y_enc"], rtol=3e-2, atol=5e-2)
+    err = (out.float().cpu() - g["y_enc"]).abs()
+    print(f"bf16 fused encoder vs reference: max|err| {err.max():.3e}, mean|err| {err.mean():.3e}")
+    assert err.mean() < 6e-3
+
+
+def test_bimamba_d256_forward_backward(golden):
+    from mamba_asr_amd.modules.mamba.bimamba import Mamba
+    g = golden("g3_d256")
+    m = Mamba(256, d_state=16, d_conv=4, expand=2, bimamba_type="v2")
+    m.load_state_dict(S.synth_like(m, 2560), strict=True)
+    m = m.to(DEV)
+    x = S.synth_input("g3_d256.x", (2, 50, 256), 2560).to(DEV).requires_grad_(True)
+    y = m(x)
+    close(y, g["y"])
+    named = list(m.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [p for _, p in named], S.synth_input("g3_d256.dy", (2, 50, 256), 2560).to(DEV))
+    close(grads[0], g["dx"])
+    for (k, _), gk in zip(named, grads[1:]):
+        close(gk, g["g." + k], rtol=3e-3, atol=3e-4)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# a4 / a5 / a6: the out_proj branch and the v1 bidirectional op, forward + backward
+# ----------------------------------------------------------------------------------------------------------
+_ARGS = ("xz", "conv_w", "conv_b", "x_proj_w", "dt_proj_w", "out_proj_w", "out_proj_b", "A", "D", "delta_bias")
+
+
+def _inner_args(g):
+    return {k: g[k].to(DEV).requires_grad_(True) for k in _ARGS}
+
+
+@pytest.mark.parametrize("which", ["fused", "ref"])
+def test_mamba_inner_with_out_proj_gradients(golden, which):
+    from mamba_asr_amd.modules.mamba import selective_scan_interface as ssi
+    g = golden("g3_inner_outproj")
+    a = _inner_args(g)
+    fn = ssi.mamba_inner_fn if which == "fused" else ssi.mamba_inner_ref
+    out = fn(a["xz"], a["conv_w"], a["conv_b"], a["x_proj_w"], a["dt_proj_w"], a["out_proj_w"], a["out_proj_b"], a["A"], None,
+             None, a["D"], delta_bias=a["delta_bias"], delta_softplus=True)
+    close(out, g["out"])
+    grads = torch.autograd.grad(out, list(a.values()), g["dout"].to(DEV))
+    for k, gk in zip(a, grads):
+        close(gk, g["d_" + k], rtol=3e-3, atol=3e-4)
+
+
+@pytest.mark.parametrize("which", ["fused", "ref"])
+def test_bimamba_v1_inner_gradients(golden, which):
+    from mamba_asr_amd.modules.mamba import selective_scan_interface as ssi
+    g, g1 = golden("g3_inner_outproj"), golden("g3_bimamba_v1")
+    a = _inner_args(g)
+    a["A_b"] = g1["A_b"].to(DEV).requires_grad_(True)
+    fn = ssi.bimamba_inner_fn if which == "fused" else ssi.bimamba_inner_ref
+    out = fn(a["xz"], a["conv_w"], a["conv_b"], a["x_proj_w"], a["dt_proj_w"], a["out_proj_w"], a["out_proj_b"], a["A"], a["A_b"],
+             None, None, a["D"], delta_bias=a["delta_bias"], delta_softplus=True)
+    close(out, g1["out"])
+    grads = torch.autograd.grad(out, list(a.values()), g["dout"].to(DEV))
+    for k, gk in zip(a, grads):
+        close(gk, g1["d_" + k], rtol=3e-3, atol=3e-4)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# a13: decoder layer gradients, decoder stack
+# ----------------------------------------------------------------------------------------------------------
+def test_decoder_layer_gradients_and_stack(golden):
+    from mamba_asr_amd.modules.Conmamba import MambaDecoder
+    g = golden("g4_decoder_stack")
+    dec = MambaDecoder(num_layers=2, d_model=64, d_ffn=128, activation=nn.ReLU, dropout=0.0, normalize_before=True,
+                       mamba_config=dict(CFG))
+    dec.load_state_dict(_params(g, "p."), strict=True)
+    dec = dec.to(DEV).train()                                       # dropout p = 0
+    tgt, mem = g["tgt"].to(DEV).requires_grad_(True), g["memory"].to(DEV).requires_grad_(True)
+    layer = dec.layers[0]
+    out_l, a, b = layer(tgt, mem)
+    assert a is None and b is None
+    close(out_l, g["layer_out"])
+    named = list(layer.named_parameters())
+    gl = torch.autograd.grad(out_l, [tgt, mem] + [p for _, p in named], g["layer_dout"].to(DEV))
+    close(gl[0], g["layer_dtgt"], rtol=3e-3, atol=3e-4)
+    close(gl[1], g["layer_dmemory"], rtol=3e-3, atol=3e-4)
+    for (k, _), gk in zip(named, gl[2:]):
+        close(gk, g["layer_g." + k], rtol=5e-3, atol=5e-4)
+    out, a, b = dec(tgt, mem)
+    assert a == [None] and b == [None]
+    close(out, g["out"])
+    named = list(dec.named_parameters())
+    go = torch.autograd.grad(out, [tgt, mem] + [p for _, p in named], g["dout"].to(DEV))
+    close(go[0], g["dtgt"], rtol=3e-3, atol=3e-4)
+    close(go[1], g["dmemory"], rtol=3e-3, atol=3e-4)
+    for (k, _), gk in zip(named, go[2:]):
+        close(gk, g["g." + k], rtol=5e-3, atol=5e-4)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# f2: single-step decode against the reference's own fallback
+# ----------------------------------------------------------------------------------------------------------
+def test_step_decode_vs_reference_fallback(golden):
+    from mamba_asr_amd.modules.mamba.bimamba import UniMamba
+    g = golden("g_step")
+    m = UniMamba(d_model=64, d_state=16, d_conv=4, expand=2)
+    m.load_state_dict(_params(g, "p."), strict=True)
+    m = m.to(DEV).eval()
+    x = g["x"].to(DEV)
+    conv_state, ssm_state = m.allocate_inference_cache(3)
+    outs = []
+    with torch.no_grad():
+        for t in range(x.shape[1]):
+            o, conv_state, ssm_state = m.step(x[:, t:t + 1], conv_state, ssm_state)
+            outs.append(o)
+    close(torch.cat(outs, 1), g["out"], rtol=2e-4, atol=2e-5)
+    close(conv_state, g["conv_state"], rtol=1e-6, atol=1e-6)
+    close(ssm_state, g["ssm_state"], rtol=2e-4, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# configs 1, 2, 5 and the north-star CTC figure, against the oracle
+# ----------------------------------------------------------------------------------------------------------
+def _cpu_state(model):
+    return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+
+
+def _ctc_case(cfg_name, layers, batch, frames, lens, seed, check_bf16_out=True, **over):
+    from dataclasses import replace
+    from mamba_asr_amd.asr import CONFIGS, ConMambaASR, samples_for_frames, synthetic_wavs
+    from oracle import conmamba_oracle as O
+    cfg = replace(CONFIGS[cfg_name], num_encoder_layers=layers, num_decoder_layers=0, **over)
+    model = ConMambaASR(cfg).to(DEV).eval()
+    wavs, _ = synthetic_wavs(batch, samples_for_frames(frames), seed, DEV)
+    lens = torch.tensor(lens, device=DEV, dtype=torch.float32)
+    for i, r in enumerate(lens.tolist()):                           # zero padding behind each utterance's end
+        wavs[i, int(round(r * wavs.shape[1])):] = 0.0
+    gen = torch.Generator().manual_seed(seed)
+    n_tok = max(4, frames // 40)
+    tokens = torch.randint(3, cfg.output_neurons, (batch, n_tok), generator=gen)
+    tok_lens = torch.linspace(1.0, 0.6, batch)
+    with torch.no_grad():
+        model.calibrate(wavs, lens)                                 # first batch: global normalisation statistics
+        (enc32, names) = _launched(lambda: model.encode(wavs, lens))
+        p32 = torch.log_softmax(model.ctc_lin(enc32), -1)
+        loss32 = model.ctc_objective(p32, tokens.to(DEV), lens, tok_lens.to(DEV))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            encbf = model.encode(wavs, lens)
+            pbf = torch.log_softmax(model.ctc_lin(encbf.float()), -1)
+        lossbf = model.ctc_objective(pbf.float(), tokens.to(DEV), lens, tok_lens.to(DEV))
+    assert "cm_scan_cl_fwd" in names
+    p = _cpu_state(model)
+    try:
+        O.load_c_oracle()
+        scan = O.selective_scan_c
+    except OSError:
+        scan = O.selective_scan
+    want = O.asr_encode(p, wavs.cpu(), lens.cpu(), layers, p["normalize.glob_mean"], p["normalize.glob_std"], scan=scan,
+                        n_fft=cfg.n_fft, win_ms=cfg.win_length)
+    logp = torch.log_softmax(torch.nn.functional.linear(want, p["ctc_lin.w.weight"], p["ctc_lin.w.bias"]), -1)
+    ref = O.ctc_loss_batchmean(logp, tokens, lens.cpu(), tok_lens)
+    d32, dbf = abs(float(loss32) - float(ref)), abs(float(lossbf) - float(ref))
+    print(f"{cfg_name} x{layers} layers, {batch} x {frames} frames: CTC oracle {float(ref):.5f} gpu fp32 {float(loss32):.5f} "
+          f"(|delta| {d32:.2e}) bf16 {float(lossbf):.5f} (|delta| {dbf:.2e}, rel {dbf / max(abs(float(ref)), 1e-9):.2e})")
+    close(enc32, want, rtol=2e-3, atol=5e-4)
+    if check_bf16_out:
+        torch.testing.assert_close(encbf.float().cpu(), want, rtol=3e-2, atol=5e-2)
+    assert d32 <= 1e-3 * max(1.0, abs(float(ref)) / 100.0), "fp32 CTC loss delta above 1e-3 (relative to 100)"
+    assert dbf <= 2e-3 * max(1.0, abs(float(ref)))
+    return d32, dbf
+
+
+def test_conmamba_small_ctc_end_to_end():
+    """BASELINE.json configs 1-2: ConMamba-small CTC (D 144, 12 layers, n_fft 400), 4 x 10 s."""
+    _ctc_case("conmamba_small_ctc", 12, 4, 1000, [1.0, 1.0, 1.0, 1.0], seed=7775)
+
+
+def test_conmamba_large_ctc_loss_18_layers():
+    """The north-star figure: ConMamba-large CTC, all 18 layers, 2 x 10 s; CTC loss delta vs the oracle."""
+    _ctc_case("conmamba_large_ctc", 18, 2, 1000, [1.0, 1.0], seed=3402, check_bf16_out=False)
+
+
+def test_ragged_wav_lens_T1000():
+    """lengths ~U(0.5, 1), L = 4000 frames -> T = 1000 scan steps.  No padding mask inside ConMamba
+    (reference Conmamba.py:635): the backward direction ingests the padding first; lengths enter the global
+    normalisation statistics and the CTC loss."""
+    _ctc_case("conmamba_large_ctc", 3, 4, 4000, [1.0, 0.83, 0.67, 0.52], seed=11)
+
+
+def test_s2s_large_dims_encoder_and_decoder():
+    """BASELINE.json config 5's kernel route: D 512, E 1024, dt_rank 32, d_ffn 2048, win 32 ms; 2 encoder layers + 1
+    Mamba decoder layer (scan over T + S steps) vs the oracle."""
+    from dataclasses import replace
+    from mamba_asr_amd.asr import CONFIGS, ConMambaASR, samples_for_frames, synthetic_wavs
+    from oracle import conmamba_oracle as O
+    cfg = replace(CONFIGS["conmambamamba_large_s2s"], num_encoder_layers=2, num_decoder_layers=1, output_neurons=200)
+    model = ConMambaASR(cfg).to(DEV).eval()
+    wavs, lens = synthetic_wavs(2, samples_for_frames(800), 5, DEV)
+    with torch.no_grad():
+        model.calibrate(wavs, lens)
+        enc = model.encode(wavs, lens)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            encbf = model.encode(wavs, lens)
+    p = _cpu_state(model)
+    O.load_c_oracle()
+    want = O.asr_encode(p, wavs.cpu(), lens.cpu(), 2, p["normalize.glob_mean"], p["normalize.glob_std"], scan=O.selective_scan_c,
+                        n_fft=cfg.n_fft, win_ms=cfg.win_length)
+    close(enc, want, rtol=2e-3, atol=5e-4)
+    torch.testing.assert_close(encbf.float().cpu(), want, rtol=3e-2, atol=5e-2)
+    # decoder: 37 target positions over the 200-step memory (cross scan length T + S = 237)
+    tgt = torch.randn(2, 37, 512, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        got, _, _ = model.Transformer.decoder(tgt.to(DEV), enc)
+    dp = {k[len("Transformer.decoder."):]: v for k, v in p.items() if k.startswith("Transformer.decoder.")}
+    close(got, O.decoder(dp, tgt, want, 1, scan=O.selective_scan_c), rtol=3e-3, atol=5e-4)

@@ -128,3 +128,69 @@ def test_ctc(golden):
     lp = g["logits"].double().log_softmax(-1)
     loss = O.ctc_loss_batchmean(lp, g["targets"], g["in_rel"], g["tg_rel"])
     close(loss, g["loss"], 1e-5, 1e-5)
+
+
+# ---- round-2 fixtures (tests/golden/make_golden_r2.py): benchmark dims, decoder stack + gradients, step decode ----
+def _synth():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("golden_synth", os.path.join(os.path.dirname(__file__), "golden", "synth.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _large_encoder_shapes():
+    """state_dict shapes of a 2-layer ConmambaEncoder at the benchmark's dims, from this package's own module (the
+    reference's keys/shapes are identical: tests/test_hip_modules.py loads reference state_dicts strict=True)."""
+    import torch.nn as nn
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    enc = ConmambaEncoder(num_layers=2, d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True, dropout=0.0,
+                          causal=False, mamba_config={"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True})
+    return {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+
+
+def test_encoder_at_benchmark_dims(golden):
+    S = _synth()
+    g = golden("g4_large")
+    p = S.synth_state(_large_encoder_shapes(), 256)
+    x = S.synth_input("g4_large.x", (16, 100, 256), 256)
+    close(O.encoder_layer(p, x[:4], "layers.0.", scan=O.selective_scan_c), g["y_layer0"][:4], 1e-3, 1e-4)
+    close(O.encoder(p, x[:4], 2, scan=O.selective_scan_c), g["y_enc"][:4], 1e-3, 1e-4)
+
+
+def test_bimamba_d256(golden):
+    from mamba_asr_amd.modules.mamba.bimamba import Mamba
+    S = _synth()
+    g = golden("g3_d256")
+    m = Mamba(256, d_state=16, d_conv=4, expand=2, bimamba_type="v2")
+    p = S.synth_like(m, 2560)
+    x = S.synth_input("g3_d256.x", (2, 50, 256), 2560)
+    close(O.bimamba_v2(p, x), g["y"], 1e-3, 2e-5)
+
+
+def test_inner_with_out_proj(golden):
+    g = golden("g3_inner_outproj")
+    out = O.mamba_inner(g["xz"], g["conv_w"], g["conv_b"], g["x_proj_w"], g["dt_proj_w"], g["out_proj_w"], g["out_proj_b"],
+                        g["A"], g["D"], g["delta_bias"])
+    close(out, g["out"], 1e-3, 2e-5)
+
+
+def test_decoder_stack(golden):
+    g = golden("g4_decoder_stack")
+    p = _params(g, "p.")
+    close(O.decoder_layer(p, g["tgt"], g["memory"], "layers.0."), g["layer_out"], 1e-3, 1e-4)
+    close(O.decoder(p, g["tgt"], g["memory"], 2), g["out"], 1e-3, 1e-4)
+
+
+def test_step_decode(golden):
+    g = golden("g_step")
+    p = _params(g, "p.")
+    x = g["x"]
+    conv_state, ssm_state = torch.zeros(3, 128, 4), torch.zeros(3, 128, 16)
+    outs = [O.mamba_step(p, x[:, t:t + 1], conv_state, ssm_state) for t in range(x.shape[1])]
+    close(torch.cat(outs, 1), g["out"], 1e-4, 1e-5)
+    close(conv_state, g["conv_state"], 1e-6, 1e-6)
+    close(ssm_state, g["ssm_state"], 1e-4, 1e-5)
+    # and the token-by-token decode equals the full-sequence unidirectional forward (what f2 promises)
+    close(torch.cat(outs, 1), O.mamba_uni(p, x), 1e-3, 1e-4)

@@ -1,0 +1,90 @@
+"""Host-side state handling (CPU): the normaliser's statistics survive a state_dict round trip and stay frozen in eval
+(sb_compat.InputNormalization), weight-copy caches notice `.data` swaps, unsupported TransformerASR
+configurations fail loudly."""
+import pytest
+import torch
+
+from mamba_asr_amd import ops
+from mamba_asr_amd import sb_compat as sb
+
+
+def _feats(seed, b=3, t=50, f=8):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(b, t, f, generator=g) * 2.0 + 1.0, torch.tensor([1.0, 0.8, 0.6])[:b]
+
+
+def test_input_normalization_round_trip_and_eval_freeze():
+    n = sb.InputNormalization(norm_type="global", update_until_epoch=4).train()
+    x1, l1 = _feats(1)
+    y_train = n(x1, l1, epoch=0)
+    assert n.count == 1 and n.glob_mean.shape == (8,)
+    mean, std = n.glob_mean.clone(), n.glob_std.clone()
+    torch.testing.assert_close(y_train, (x1 - mean) / std)
+    sd = n.state_dict()
+    assert int(sd["count_buf"]) == 1
+    fresh = sb.InputNormalization(norm_type="global", update_until_epoch=4).eval()
+    fresh.load_state_dict(sd, strict=True)                      # (1,) placeholder buffers take the checkpoint's shape
+    assert fresh.count == 1
+    x2, l2 = _feats(2)
+    y = fresh(x2, l2, epoch=0)                                  # a different batch, eval: statistics must not move
+    torch.testing.assert_close(fresh.glob_mean, mean)
+    torch.testing.assert_close(fresh.glob_std, std)
+    torch.testing.assert_close(y, (x2 - mean) / std)
+    assert fresh.count == 1
+    # training resumes the running average where it stopped (weight 1 / (count + 1))
+    fresh.train()
+    fresh(x2, l2, epoch=0)
+    assert fresh.count == 2 and not torch.allclose(fresh.glob_mean, mean)
+    # beyond update_until_epoch the statistics are frozen in training too
+    m2 = fresh.glob_mean.clone()
+    fresh(x1, l1, epoch=4)
+    torch.testing.assert_close(fresh.glob_mean, m2)
+
+
+def test_input_normalization_eval_before_any_update_is_identity():
+    n = sb.InputNormalization(norm_type="global").eval()
+    x, l = _feats(3)
+    torch.testing.assert_close(n(x, l), x)                      # mean 0 / std 1 until something updates them
+    assert n.count == 0
+    n.update_statistics(x, l)                                   # the explicit calibration entry point
+    assert n.count == 1 and n.glob_mean.shape == (8,)
+
+
+def test_whole_model_state_dict_round_trip_keeps_fused_path_eligible():
+    from mamba_asr_amd.asr import ASRConfig, ConMambaASR
+    cfg = ASRConfig("tiny", d_model=32, d_ffn=64, num_encoder_layers=1, n_fft=400, seed=3)
+    a = ConMambaASR(cfg).train()
+    x, l = _feats(4, b=2, t=30, f=80)
+    a.normalize(x, l[:2], epoch=0)
+    b = ConMambaASR(cfg).eval()
+    b.load_state_dict(a.state_dict(), strict=True)
+    assert b.normalize.count == 1                               # asr.encode's fused-path condition (count > 0) holds
+    torch.testing.assert_close(b.normalize.glob_mean, a.normalize.glob_mean)
+
+
+def test_cast_cache_sees_data_swap_and_invalidate():
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    c1 = ops.cast_cached(p, torch.bfloat16)
+    assert ops.cast_cached(p, torch.bfloat16) is c1
+    p.data = torch.randn(4, 4)                                  # storage swap: _version unchanged, data_ptr changes
+    c2 = ops.cast_cached(p, torch.bfloat16)
+    torch.testing.assert_close(c2.float(), p.detach().to(torch.bfloat16).float())
+    p.data.copy_(torch.randn(4, 4))                             # write THROUGH .data: invisible -> invalidate_caches
+    lin = torch.nn.Linear(4, 4)
+    lin.weight = p
+    ops.invalidate_caches(lin)
+    c3 = ops.cast_cached(p, torch.bfloat16)
+    torch.testing.assert_close(c3.float(), p.detach().to(torch.bfloat16).float())
+    with torch.no_grad():
+        p.add_(1.0)                                             # in-place on the parameter itself: version bump
+    torch.testing.assert_close(ops.cast_cached(p, torch.bfloat16).float(), p.detach().to(torch.bfloat16).float())
+
+
+def test_transformer_asr_rejects_unimplemented_attention_type():
+    from mamba_asr_amd.modules.TransformerASR import TransformerASR
+    cfg = {"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True}
+    with pytest.raises(NotImplementedError):
+        TransformerASR(tgt_vocab=31, input_size=640, d_model=32, num_encoder_layers=1, num_decoder_layers=0, d_ffn=64,
+                       encoder_module="conmamba", normalize_before=True, causal=False, mamba_config=cfg)   # default regularMHA
+    TransformerASR(tgt_vocab=31, input_size=640, d_model=32, num_encoder_layers=1, num_decoder_layers=0, d_ffn=64,
+                   encoder_module="conmamba", attention_type="RelPosMHAXL", normalize_before=True, causal=False, mamba_config=cfg)

@@ -15,7 +15,7 @@ gen = torch.Generator().manual_seed(1)
 tokens = torch.randint(3, 31, (2, 140), generator=gen)
 tl = torch.tensor([1.0, 0.9])
 with torch.no_grad():
-    model.features(wavs, lens)
+    model.calibrate(wavs, lens)
     l32 = model.ctc_objective(model.forward_ctc(wavs, lens), tokens.to(dev), lens, tl.to(dev))
     with torch.autocast("cuda", dtype=torch.bfloat16):
         pbf = model.forward_ctc(wavs, lens)
