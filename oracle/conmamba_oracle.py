@@ -392,8 +392,9 @@ def encoder(p, x, num_layers, prefix="", scan=selective_scan, kernel_size=31):
     return _ln(x, p[prefix + "norm.norm.weight"].to(x.dtype), p[prefix + "norm.norm.bias"].to(x.dtype), 1e-6)
 
 
-def decoder_layer(p, tgt, memory, prefix="", scan=selective_scan):
-    """MambaDecoderLayer.forward with normalize_before=True, Conmamba.py:914-953."""
+def decoder_layer(p, tgt, memory, prefix="", scan=selective_scan, act=F.relu):
+    """MambaDecoderLayer.forward with normalize_before=True, Conmamba.py:914-953.  ``act`` = the layer's activation
+    (class default nn.ReLU, Conmamba.py:846; the S2S recipes pass GELU, hparams/S2S/conmambamamba_large.yaml:259)."""
     g = lambda k: p[prefix + k].to(tgt.dtype)
     t1 = _ln(tgt, g("norm1.norm.weight"), g("norm1.norm.bias"), 1e-6)
     tgt = tgt + mamba_uni(p, t1, scan, prefix + "self_mamba.")                       # :920-923
@@ -401,14 +402,14 @@ def decoder_layer(p, tgt, memory, prefix="", scan=selective_scan):
     cat = torch.cat([memory, t1], dim=1)
     tgt = tgt + mamba_uni(p, cat, scan, prefix + "cross_mamba.")[:, -t1.shape[1]:]   # :934-937
     t1 = _ln(tgt, g("norm3.norm.weight"), g("norm3.norm.bias"), 1e-6)
-    h = F.relu(F.linear(t1, g("pos_ffn.ffn.0.weight"), g("pos_ffn.ffn.0.bias")))
+    h = act(F.linear(t1, g("pos_ffn.ffn.0.weight"), g("pos_ffn.ffn.0.bias")))
     return tgt + F.linear(h, g("pos_ffn.ffn.3.weight"), g("pos_ffn.ffn.3.bias"))     # :946-949
 
 
-def decoder(p, tgt, memory, num_layers, prefix="", scan=selective_scan):
+def decoder(p, tgt, memory, num_layers, prefix="", scan=selective_scan, act=F.relu):
     """MambaDecoder.forward, Conmamba.py:1017-1031: the layers, then the final LayerNorm (eps 1e-6)."""
     for i in range(num_layers):
-        tgt = decoder_layer(p, tgt, memory, f"{prefix}layers.{i}.", scan)
+        tgt = decoder_layer(p, tgt, memory, f"{prefix}layers.{i}.", scan, act)
     return _ln(tgt, p[prefix + "norm.norm.weight"].to(tgt.dtype), p[prefix + "norm.norm.bias"].to(tgt.dtype), 1e-6)
 
 

@@ -13,8 +13,7 @@ def large_model():
     cfg = CONFIGS["conmamba_large_ctc"]
     model = ConMambaASR(cfg).to(DEV).eval()
     wavs, lens = synthetic_wavs(6, samples_for_frames(4000), cfg.seed, DEV)
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        model.encode(wavs, lens)                              # first batch fixes the global normalisation statistics
+    model.calibrate(wavs, lens)                               # first batch fixes the global normalisation statistics
     return model, wavs, lens
 
 
