@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 3
+#define CM_ABI_VERSION 4
 
 /* error codes */
 #define CM_OK            0
@@ -102,6 +102,15 @@ typedef struct cm_scan_fwd_args {
     int64_t B_bs, B_ns;          /* batch / state strides of B                            */
     int64_t C_bs, C_ns;
     void   *stream;
+    const float *h0;         /* (batch, dim, dstate) fp32, contiguous, or NULL: the state the
+                                recurrence starts from instead of zero (in scan order: before
+                                step 0, or behind step seqlen-1 with reverse_time).  Forward only
+                                (cm_selective_scan_bwd rejects it).  With it, a sequence cut into
+                                time shards gives the unsplit result: shard k starts from shard
+                                k-1's last state x[:, :, last chunk, 1::2] -- the carry the
+                                time-split scan across GPUs exchanges (no
+                                reference counterpart: the reference has no sequence parallelism,
+                                SURVEY.md §5)                                               */
 } cm_scan_fwd_args;
 
 int cm_selective_scan_fwd(const cm_scan_fwd_args *args);

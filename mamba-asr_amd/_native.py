@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -27,7 +27,7 @@ class ScanFwdArgs(C.Structure):
         ("out", vp), ("out_z", vp), ("x", fp),
         ("u_bs", i64), ("u_ds", i64), ("delta_bs", i64), ("delta_ds", i64), ("z_bs", i64), ("z_ds", i64),
         ("out_bs", i64), ("out_ds", i64), ("B_bs", i64), ("B_ns", i64), ("C_bs", i64), ("C_ns", i64),
-        ("stream", vp),
+        ("stream", vp), ("h0", fp),
     ]
 
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void scan_fwd_kernel(const cm_scan_fwd_ar
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         Ap[i] = p.A[(int64_t)e_c * N + sg * NS + i] * CM_LOG2E;
-        h[i] = 0.f;
+        h[i] = p.h0 ? p.h0[((int64_t)b * dim + e_c) * N + sg * NS + i] : 0.f;      // carry of a time-split scan, else zero
     }
     const float Dv = p.D ? p.D[e_c] : 0.f;
     const float bias = p.delta_bias ? p.delta_bias[e_c] : 0.f;

@@ -18,6 +18,7 @@ extern "C" int cm_selective_scan_bwd(const cm_scan_bwd_args *args) {
                "scan_bwd: u/delta/A/B/C/x/dout must be non-NULL");
     CM_REQUIRE(a.du && a.ddelta && a.dA && a.dB && a.dC, CM_EINVAL, "scan_bwd: du/ddelta/dA/dB/dC must be non-NULL");
     CM_REQUIRE(!f.z || a.dz, CM_EINVAL, "scan_bwd: dz is NULL although z is given");
+    CM_REQUIRE(f.h0 == nullptr, CM_EUNSUPPORTED, "scan_bwd: an initial state (h0) is a forward-only feature");
     const int vec = f.io_dtype == CM_F32 ? 4 : 8;
     auto rows_ok = [&](const void *p, int64_t s0, int64_t s1) {
         return !p || (cm_aligned(p, 16) && s0 % vec == 0 && s1 % vec == 0);

@@ -128,10 +128,12 @@ def _fill_scan_args(a, u, delta, A, B, C_, D, z, delta_bias, delta_softplus, rev
 
 
 def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
-                       reverse=False, need_out=True, need_x=True, out_z_buf: Optional[torch.Tensor] = None):
+                       reverse=False, need_out=True, need_x=True, out_z_buf: Optional[torch.Tensor] = None,
+                       h0: Optional[torch.Tensor] = None):
     """-> (out, x, out_z): what selective_scan_cuda.fwd returns (selective_scan_interface.py:42).
     ``out`` is the pre-gate output (None when z is given and need_out is False), ``x`` the
-    checkpoint tensor (batch, dim, nchunks, 2*dstate) or None, ``out_z`` the gated output or None."""
+    checkpoint tensor (batch, dim, nchunks, 2*dstate) or None, ``out_z`` the gated output or None.
+    ``h0`` (batch, dim, dstate) fp32: state the recurrence starts from (time-split scans, seqpar.py)."""
     _dev_check(u, delta, A, B, C, D, z, delta_bias)
     u, delta, z = _time_contig(u), _time_contig(delta), _time_contig(z)
     if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
@@ -152,6 +154,12 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
             raise RuntimeError("out_z_buf must be a time-contiguous (batch, dim, seqlen) tensor of u's dtype")
     x = torch.empty((b, d, num_chunks(l), 2 * A.shape[1]), dtype=torch.float32, device=u.device) if need_x else None
     a.out, a.out_z, a.x = _ptr(out), _ptr(out_z), _ptr(x)
+    if h0 is not None:
+        _dev_check(h0)
+        if tuple(h0.shape) != (b, d, A.shape[1]):
+            raise RuntimeError(f"h0 must be (batch, dim, dstate) = {(b, d, A.shape[1])}, got {tuple(h0.shape)}")
+        h0 = _f32c(h0)
+        a.h0 = _ptr(h0)
     a.out_bs, a.out_ds = d * l, l
     if out_z is not None:
         if out is not None and (out_z.stride(0), out_z.stride(1)) != (d * l, l):

@@ -102,12 +102,14 @@ def softplus(x: torch.Tensor) -> torch.Tensor:
 
 
 def selective_scan(u, delta, A, B, C, D=None, z=None, delta_bias=None,
-                   delta_softplus=False, return_last_state=False, work_dtype=None):
+                   delta_softplus=False, return_last_state=False, work_dtype=None, initial_state=None):
     """Restates selective_scan_ref (ssi.py:91-157), real A, variable B/C.
 
     u, delta, z: (b, d, l); A: (d, n); B, C: (b, n, l) or (b, g, n, l); D, delta_bias: (d).
     Computation dtype = fp32 (like ssi.py:107-123) unless work_dtype is given (tests use
     float64 to get a tighter oracle).  Output is cast back to u.dtype (ssi.py:156).
+    ``initial_state`` (b, d, n) is NOT in the reference (its x starts at zero, ssi.py:124): it is the one-line
+    generalisation the time-split tests need -- with it, scanning a sequence in two pieces equals scanning it whole.
     """
     wd = work_dtype or torch.float32
     in_dtype = u.dtype
@@ -125,7 +127,7 @@ def selective_scan(u, delta, A, B, C, D=None, z=None, delta_bias=None,
         Bw = Bw.repeat_interleave(dim // Bw.shape[1], dim=1)
     if Cw.dim() == 4:                                # ssi.py:136
         Cw = Cw.repeat_interleave(dim // Cw.shape[1], dim=1)
-    h = torch.zeros(bsz, dim, nstate, dtype=wd)      # ssi.py:124
+    h = torch.zeros(bsz, dim, nstate, dtype=wd) if initial_state is None else initial_state.to(wd).clone()   # ssi.py:124
     y = torch.empty(bsz, dim, length, dtype=wd)
     for t in range(length):                          # ssi.py:138-151
         dt_t = dt[:, :, t]                           # (b d)
