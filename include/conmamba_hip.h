@@ -138,9 +138,19 @@ typedef struct cm_scan_bwd_args {
     float *dC;
     float *dD;               /* (dim) or NULL                                             */
     float *ddelta_bias;      /* (dim) or NULL                                             */
+    void  *workspace;        /* optional scratch of cm_selective_scan_bwd_workspace_bytes()
+                                bytes (16-byte aligned), or NULL.  With it every reduction
+                                across workgroups (dB / dC over channel tiles; dA, dD,
+                                ddelta_bias over the batch) is a per-workgroup partial + a
+                                second kernel that sums in a FIXED order: gradients are
+                                bit-identical from run to run.  Without it they are fp32
+                                atomics, as in the CUDA kernels the reference binds          */
+    int64_t workspace_bytes; /* size of workspace; 0 with NULL                            */
 } cm_scan_bwd_args;
 
 int cm_selective_scan_bwd(const cm_scan_bwd_args *args);
+/* bytes of workspace the deterministic path needs for these sizes (uses batch, dim, seqlen, dstate only) */
+int64_t cm_selective_scan_bwd_workspace_bytes(const cm_scan_bwd_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * Causal depthwise conv1d (+ optional SiLU) — replaces causal_conv1d_cuda.causal_conv1d_fwd /
@@ -166,6 +176,10 @@ typedef struct cm_conv_args {
     float       *dbias;                    /* (dim) fp32 or NULL, accumulated               */
     int64_t dy_bs, dy_ds, dx_bs, dx_ds;
     void   *stream;
+    float  *workspace;                     /* backward, optional: batch * dim * (width + 1) floats, or NULL.  With it the
+                                              per-(batch, channel) partial sums of dweight / dbias are stored and summed over
+                                              the batch in a fixed order by a second kernel (bit-identical from run to run);
+                                              without it they are fp32 atomics                                          */
 } cm_conv_args;
 
 int cm_causal_conv1d_fwd(const cm_conv_args *args);

@@ -38,6 +38,7 @@ class ScanBwdArgs(C.Structure):
         ("du", vp), ("ddelta", vp), ("dz", vp),
         ("du_bs", i64), ("du_ds", i64), ("ddelta_bs", i64), ("ddelta_ds", i64), ("dz_bs", i64), ("dz_ds", i64),
         ("dA", fp), ("dB", fp), ("dC", fp), ("dD", fp), ("ddelta_bias", fp),
+        ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -49,7 +50,7 @@ class ConvArgs(C.Structure):
         ("x_bs", i64), ("x_ds", i64), ("y_bs", i64), ("y_ds", i64),
         ("dy", vp), ("dx", vp), ("dweight", fp), ("dbias", fp),
         ("dy_bs", i64), ("dy_ds", i64), ("dx_bs", i64), ("dx_ds", i64),
-        ("stream", vp),
+        ("stream", vp), ("workspace", fp),
     ]
 
 
@@ -224,6 +225,7 @@ SYMBOLS = [
     ("cm_scan_set_split", C.c_int, [C.c_int]),
     ("cm_selective_scan_fwd", C.c_int, [C.POINTER(ScanFwdArgs)]),
     ("cm_selective_scan_bwd", C.c_int, [C.POINTER(ScanBwdArgs)]),
+    ("cm_selective_scan_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanBwdArgs)]),
     ("cm_causal_conv1d_fwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_debug_set", C.c_int, [C.c_int]),

@@ -150,9 +150,22 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const cm_conv_args p) {
     if (threadIdx.x <= W) {
         const int k = threadIdx.x;
         const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-        if (k < W) atomicAdd(p.dweight + d * W + k, v);
+        if (p.workspace) p.workspace[((int64_t)b * p.dim + d) * (W + 1) + k] = v;      // summed over the batch by conv_bwd_reduce_kernel
+        else if (k < W) atomicAdd(p.dweight + d * W + k, v);
         else if (p.dbias) atomicAdd(p.dbias + d, v);
     }
+}
+
+// deterministic path: dweight[d][k] += sum_b partial[b][d][k] in batch order (k == W: dbias)
+template <int W>
+__global__ __launch_bounds__(256) void conv_bwd_reduce_kernel(const cm_conv_args p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.dim * (W + 1)) return;
+    const int d = i / (W + 1), k = i % (W + 1);
+    float acc = 0.f;
+    for (int b = 0; b < p.batch; ++b) acc += p.workspace[((int64_t)b * p.dim + d) * (W + 1) + k];
+    if (k < W) p.dweight[d * W + k] += acc;
+    else if (p.dbias) p.dbias[d] += acc;
 }
 
 template <typename IO, int W>
@@ -176,6 +189,8 @@ int launch_bwd(const cm_conv_args &a) {
     dim3 grid(a.dim, a.batch);
     if (a.reverse_time) hipLaunchKernelGGL((conv_bwd_kernel<IO, W, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_bwd_kernel<IO, W, false>), grid, dim3(256), 0, st, a);
+    if (a.workspace)
+        hipLaunchKernelGGL((conv_bwd_reduce_kernel<W>), dim3((a.dim * (W + 1) + 255) / 256), dim3(256), 0, st, a);
     return cm_launch_status("cm_causal_conv1d_bwd");
 }
 

@@ -16,8 +16,10 @@
 //              tiles), per-lane dA/dD/ddelta_bias partial sums (registers, one atomic per lane at
 //              the end) and dB/dC contributions.
 // dB[n,t], dC[n,t] sum over channels: DPP reduction over the channel lanes of a 16-lane row,
-// 16 partials per workgroup through LDS (double-buffered), then one fp32 atomic per
-// (workgroup, n, t).
+// 16 partials per workgroup through LDS (double-buffered), then per (workgroup, n, t) either one
+// fp32 atomic, or -- with a workspace -- a plain store of the workgroup's partial that
+// scan_bwd_reduce_kernel sums over the workgroups in a fixed order (deterministic gradients); the
+// per-channel dA / dD / ddelta_bias partials of a batch element are handled the same way.
 #pragma once
 #include "cm_common.h"
 
@@ -135,6 +137,9 @@ __global__ __launch_bounds__(kBwdThreads, NS <= 2 ? 2 : 1) void scan_bwd_kernel(
     float dDacc = 0.f, dbacc = 0.f;
     const int nchunks = (L + CK - 1) / CK;
     int pb_sel = 0;
+    // deterministic path: per-workgroup partials (layout: scan_bwd_ws)
+    float *wsBC = reinterpret_cast<float *>(p.workspace);        // [2][gridDim.x][batch][N][L]
+    const int64_t ws_bc_stride = (int64_t)gridDim.x * gridDim.y * N * L;
 
     for (int ic = 0; ic < nchunks; ++ic) {
         const int c = REV ? ic : nchunks - 1 - ic;               // chunks in descending processing order
@@ -401,7 +406,10 @@ __global__ __launch_bounds__(kBwdThreads, NS <= 2 ? 2 : 1) void scan_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < NPART; ++k) acc += src[k * (N * SBK)];
                 const int t = t0 + tbs + j;
-                if (t < L) atomicAdd((which ? p.dC : p.dB) + ((int64_t)b * N + n) * L + t, acc);
+                if (t < L) {
+                    if (wsBC) wsBC[which * ws_bc_stride + (((int64_t)blockIdx.x * gridDim.y + b) * N + n) * L + t] = acc;
+                    else atomicAdd((which ? p.dC : p.dB) + ((int64_t)b * N + n) * L + t, acc);
+                }
             }
             pb_sel ^= 1;
         }
@@ -423,7 +431,20 @@ __global__ __launch_bounds__(kBwdThreads, NS <= 2 ? 2 : 1) void scan_bwd_kernel(
         }
     }
     // ---------------- per-channel parameter gradients
-    if (e_ok) {
+    if (wsBC) {
+        float *wsA = wsBC + 2 * ws_bc_stride;                    // [batch][dim][N]
+        float *wsD = wsA + (int64_t)gridDim.y * dim * N;         // [batch][dim]
+        float *wsb = wsD + (int64_t)gridDim.y * dim;             // [batch][dim]
+        const float dDq = cm_group_sum<4>(dDacc), dbq = cm_group_sum<4>(dbacc);   // the 4 owner lanes (sg 0..3) of the channel
+        if (e_ok) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) wsA[((int64_t)b * dim + e) * N + sg * NS + i] = dAacc[i];
+            if (sg == 0) {
+                wsD[(int64_t)b * dim + e] = dDq;
+                wsb[(int64_t)b * dim + e] = dbq;
+            }
+        }
+    } else if (e_ok) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) atomicAdd(p.dA + (int64_t)e * N + sg * NS + i, dAacc[i]);
         if (sg < 4) {
@@ -431,6 +452,44 @@ __global__ __launch_bounds__(kBwdThreads, NS <= 2 ? 2 : 1) void scan_bwd_kernel(
             if (p.ddelta_bias) atomicAdd(p.ddelta_bias + e, dbacc);
         }
     }
+}
+
+// second pass of the deterministic path: fixed-order sums of the per-workgroup partials, ACCUMULATED into the outputs
+__global__ __launch_bounds__(256) void scan_bwd_reduce_kernel(const cm_scan_bwd_args p, const int gx) {
+    const cm_scan_fwd_args &f = p.fwd;
+    const int64_t nbc = (int64_t)f.batch * f.dstate * f.seqlen, na = (int64_t)f.dim * f.dstate;
+    const float *wsBC = reinterpret_cast<const float *>(p.workspace);
+    const int64_t ws_bc_stride = (int64_t)gx * nbc;
+    const float *wsA = wsBC + 2 * ws_bc_stride, *wsD = wsA + (int64_t)f.batch * na, *wsb = wsD + (int64_t)f.batch * f.dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * nbc + na + 2 * f.dim; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < 2 * nbc) {                                       // dB, dC: sum over the channel-tile workgroups
+            const int which = i >= nbc;
+            const int64_t j = i - which * nbc;
+            float acc = 0.f;
+            for (int g = 0; g < gx; ++g) acc += wsBC[which * ws_bc_stride + (int64_t)g * nbc + j];
+            (which ? p.dC : p.dB)[j] += acc;
+        } else if (i < 2 * nbc + na) {                           // dA: sum over the batch
+            const int64_t j = i - 2 * nbc;
+            float acc = 0.f;
+            for (int b = 0; b < f.batch; ++b) acc += wsA[(int64_t)b * na + j];
+            p.dA[j] += acc;
+        } else {                                                 // dD, ddelta_bias: sum over the batch
+            const int64_t j = i - 2 * nbc - na;
+            const int which = j >= f.dim;
+            const int e = (int)(j - which * f.dim);
+            float *dst = which ? p.ddelta_bias : p.dD;
+            if (!dst) continue;
+            const float *src = which ? wsb : wsD;
+            float acc = 0.f;
+            for (int b = 0; b < f.batch; ++b) acc += src[(int64_t)b * f.dim + e];
+            dst[e] += acc;
+        }
+    }
+}
+
+// workspace bytes of the deterministic path for a launch with `gx` channel-tile workgroups per batch element
+inline int64_t scan_bwd_ws_bytes(const cm_scan_fwd_args &f, int gx) {
+    return 4 * (2 * (int64_t)gx * f.batch * f.dstate * f.seqlen + (int64_t)f.batch * f.dim * f.dstate + 2 * (int64_t)f.batch * f.dim);
 }
 
 template <typename IO, int S>
@@ -445,6 +504,11 @@ int launch_scan_bwd(const cm_scan_bwd_args &a, bool vecok) {
     const size_t smem = scan_bwd_smem<IO, S>(S * NS);
     dim3 grid((a.fwd.dim + kBwdWaves * CPW - 1) / (kBwdWaves * CPW), a.fwd.batch);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.fwd.stream);
+    if (a.workspace && a.workspace_bytes < scan_bwd_ws_bytes(a.fwd, (int)grid.x)) {
+        cm_set_error("scan_bwd: workspace of %lld bytes is smaller than the %lld this launch needs", (long long)a.workspace_bytes,
+                     (long long)scan_bwd_ws_bytes(a.fwd, (int)grid.x));
+        return CM_EINVAL;
+    }
     auto go = [&](auto kern) -> int {
         if (smem > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -455,6 +519,11 @@ int launch_scan_bwd(const cm_scan_bwd_args &a, bool vecok) {
             }
         }
         hipLaunchKernelGGL(kern, grid, dim3(kBwdThreads), smem, st, a, (int)vecok);
+        if (a.workspace) {
+            const int64_t n = 2 * (int64_t)a.fwd.batch * a.fwd.dstate * a.fwd.seqlen + (int64_t)a.fwd.dim * a.fwd.dstate + 2 * a.fwd.dim;
+            const int64_t blocks = (n + 255) / 256;
+            hipLaunchKernelGGL(scan_bwd_reduce_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, st, a, (int)grid.x);
+        }
         return cm_launch_status("cm_selective_scan_bwd");
     };
     if (a.fwd.reverse_time) return go(scan_bwd_kernel<IO, BC, S, NS, true>);

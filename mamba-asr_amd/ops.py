@@ -18,6 +18,13 @@ from . import _native as N
 _DT = {torch.float32: N.CM_F32, torch.bfloat16: N.CM_BF16, torch.float16: N.CM_F16}
 
 
+# Gradient reductions across workgroups (scan backward: dA / dB / dC / dD / ddelta_bias; causal conv backward: dweight /
+# dbias) run as per-workgroup partials + a fixed-order second pass: bit-identical gradients from run to run (what
+# SURVEY.md §8d config 4's 1-GPU vs 8-GPU comparison needs to be meaningful at fp32).  CM_DETERMINISTIC=0 switches to
+# the fp32 atomics the CUDA kernels behind the reference use (no workspace, order-dependent last bits).
+DETERMINISTIC = os.environ.get("CM_DETERMINISTIC", "1") == "1"
+
+
 # When set to a list, every native launch is bracketed by HIP events recorded on the stream the kernel
 # is launched on; entries are (kernel_name, start_event, end_event, units).  Used by bench.py's roofline leg.
 LAUNCH_LOG: Optional[list] = None
@@ -214,6 +221,10 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
     if z is not None:
         a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
     a.dA, a.dB, a.dC, a.dD, a.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias)
+    if DETERMINISTIC:
+        nbytes = int(N.lib().cm_selective_scan_bwd_workspace_bytes(ct.byref(a)))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)          # caching allocator: 16-byte aligned
+        a.workspace, a.workspace_bytes = _ptr(ws), nbytes
     _launch("cm_selective_scan_bwd", N.lib().cm_selective_scan_bwd, a, units=b * l)
     return du, ddelta, dA, dB, dC, dD, dbias, (dz if z is not None else None), out_z
 
@@ -257,6 +268,9 @@ def causal_conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx: Optiona
     a.dy, a.dx, a.dweight, a.dbias = _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db)
     a.dy_bs, a.dy_ds, a.dx_bs, a.dx_ds = dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1)
     a.stream = _stream()
+    if DETERMINISTIC:
+        ws = torch.empty((b * d * (w.shape[1] + 1),), dtype=torch.float32, device=x.device)
+        a.workspace = _ptr(ws)
     _launch("cm_causal_conv1d_bwd", N.lib().cm_causal_conv1d_bwd, a, units=b * l)
     return dx, dw, db
 
