@@ -155,14 +155,25 @@ def run_train(a, cfg, dev, rank, world, use_dist):
     model = ConMambaASR(cfg).to(dev)
     aug = sb.Augmenter(augmentations=[sb.SpectrogramDrop(6, 12, 1, 5, "mean", 1), sb.SpectrogramDrop(10, 20, 1, 3, "mean", 2)])
 
+    s2s = cfg.num_decoder_layers > 0                          # config 5: Mamba decoder + joint CTC / label-smoothed KL loss
+
     class ASR(Brain):
         def compute_forward(self, batch, stage):
             wavs, lens, tokens, tlens = batch
-            return self.modules["asr"].forward_ctc(wavs, lens, epoch=0, augment=aug if stage == Stage.TRAIN else None)
+            m, a_ = self.modules["asr"], (aug if stage == Stage.TRAIN else None)
+            if s2s:                                            # train_S2S.py:285-320: <bos> + tokens into the decoder
+                bos = torch.cat([torch.ones_like(tokens[:, :1]), tokens], 1)
+                return m.forward_s2s(wavs, lens, bos, epoch=0, augment=a_)
+            return m.forward_ctc(wavs, lens, epoch=0, augment=a_)
 
-        def compute_objectives(self, p_ctc, batch, stage):
+        def compute_objectives(self, pred, batch, stage):
             wavs, lens, tokens, tlens = batch
-            return self.modules["asr"].ctc_objective(p_ctc, tokens, lens, tlens)
+            m = self.modules["asr"]
+            if s2s:                                            # train_S2S.py:518-529: 0.3 CTC + 0.7 KL against tokens + <eos>
+                p_ctc, p_seq = pred
+                eos = torch.cat([tokens, torch.full_like(tokens[:, :1], 2)], 1)
+                return m.s2s_objective(p_ctc.float(), p_seq.float(), tokens, tlens, eos, tlens, lens)
+            return m.ctc_objective(pred, tokens, lens, tlens)
 
         def on_fit_batch_end(self, batch, outputs, loss, should_step):
             if should_step:
@@ -179,7 +190,9 @@ def run_train(a, cfg, dev, rank, world, use_dist):
     brain.modules.train()
     wavs, lens = make_batch(a, cfg, rank, dev)
     g = torch.Generator().manual_seed(rank)
-    tokens = torch.randint(3, cfg.output_neurons, (a.batch, a.frames // 8), generator=g).to(dev)     # ~12.5 chars/s
+    # CTC recipe: characters, ~12.5 per second; S2S recipe: 5000 word pieces, ~2.5 per second (S ~ 400 at 160 s: SURVEY §8d)
+    n_tok = a.frames // 40 if s2s else a.frames // 8
+    tokens = torch.randint(3, cfg.output_neurons, (a.batch, n_tok), generator=g).to(dev)
     batch = (wavs, lens, tokens, lens.clone())
 
     def fence():
@@ -223,11 +236,12 @@ def run_train(a, cfg, dev, rank, world, use_dist):
                     "kernel": "scan_bwd_kernel (cm_selective_scan_bwd, one direction per launch)",
                     "avg_launch_us": round(avg_ms * 1e3, 1), "launches_per_step": len(ts), "alg_bytes_per_launch": alg}
     if rank == 0:
-        line = {"metric": f"training audio-frames/sec ({cfg.name}, L={a.frames}, fwd+bwd+AdamW)", "value": round(value, 1),
+        line = {"metric": f"training audio-frames/sec ({cfg.name}, L={a.frames}, fwd+bwd+AdamW" + (", encoder + Mamba decoder, 0.3 CTC + 0.7 KL)" if s2s else ")"),
+                "value": round(value, 1),
                 "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic",
-                "config": {"workload": f"{cfg.name}: CTC training micro-batch, {a.batch} utterances x {a.frames} frames per GPU, "
+                "config": {"workload": f"{cfg.name}: {'S2S' if s2s else 'CTC'} training micro-batch, {a.batch} utterances x {a.frames} frames per GPU, "
                                        f"SpecAugment, grad_accumulation_factor {a.accum}, AdamW + Noam, clip 5.0",
                            "global_batch": world * a.batch, "frames_per_utterance": a.frames,
                            "parallelism": f"dp{world}: gradient exchange every {a.accum} micro-batches "
