@@ -222,6 +222,12 @@ typedef struct cm_scan_cl_dir {
                                 (dim, 16) fp32 zero-padded, dim a multiple of 8 (bf16) / 4 (fp32), and the row-group
                                 kernel (csrc/scan_rows_fwd.hip) runs                                                */
     int64_t xdbl_bs, xdbl_ts;/* batch / step strides of xdbl in elements (multiples of 8 for bf16, 4 for fp32)       */
+    /* xdbl mode only, all optional, (batch, dim, 16) fp32 contiguous -- the carry interface of the time-split scan
+       (no reference counterpart): */
+    const float *h0;         /* state the recurrence starts from (in this direction's scan order) instead of zero     */
+    float       *h_last;     /* out: state after the last processed step                                               */
+    float       *decay;      /* out: product over the sequence of exp(delta' A), i.e. what a state entering this shard
+                                is multiplied by on its way through it                                                */
 } cm_scan_cl_dir;
 
 typedef struct cm_scan_cl_args {

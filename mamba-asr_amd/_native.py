@@ -61,6 +61,7 @@ class ScanClDir(C.Structure):
         ("u_bs", i64), ("u_ts", i64), ("delta_bs", i64), ("delta_ts", i64), ("out_bs", i64), ("out_ts", i64),
         ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("dt_rank", i32),
         ("xdbl", vp), ("xdbl_bs", i64), ("xdbl_ts", i64),
+        ("h0", fp), ("h_last", fp), ("decay", fp),
     ]
 
 

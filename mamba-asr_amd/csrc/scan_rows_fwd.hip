@@ -167,6 +167,12 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             Wdt8 = __builtin_convertvector(f32x8{lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc}, bf16x8);
         }
     }
+    if (d.h0) {                                                   // carry of a time-split scan (seqpar.py), else zero
+        const float4 h4 = *reinterpret_cast<const float4 *>(d.h0 + ((int64_t)b * E + cc) * 16 + 4 * g);
+        h01 = f32x2{h4.x, h4.y};
+        h23 = f32x2{h4.z, h4.w};
+    }
+    float dsum = 0.f;                                             // sum of this lane's owned delta' (for the decay output)
     const float bias = d.delta_bias ? d.delta_bias[cc] : 0.f;
     const float Dv = d.D ? d.D[cc] : 0.f;
     float uq[4], zq[4];                                           // (u, z) of the lane's 4 owned steps of the staged block
@@ -208,6 +214,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             float dv = acc[i] + bias;
             if (softplus && ABL != 3) dv = softplus_rows(dv);
             if (ragged) dv = tb + 4 * g + i < T ? dv : 0.f;       // padded steps: a = 1, b = 0 (state passes through)
+            dsum += dv;
             const float uv = ld_io(ut + i * 64);
             uq[i] = uv;
             zq[i] = has_z ? ld_io(zt + i * 64) : 0.f;
@@ -319,6 +326,18 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         const int t_old = t_cur, x_old = x_cur;
         t_cur = t_nxt; t_nxt = t_fill; t_fill = t_old;
         x_cur = x_nxt; x_nxt = x_fill; x_fill = x_old;
+    }
+    // ---- carry outputs of a time shard: last state, and the factor a state entering the shard is multiplied by
+    if (d.h_last && c_ok)
+        *reinterpret_cast<float4 *>(d.h_last + ((int64_t)b * E + c) * 16 + 4 * g) = make_float4(h01.x, h01.y, h23.x, h23.y);
+    if (d.decay) {
+        // sum of delta' over the sequence for channel c16: this lane's owned steps + the other three lane groups', through the
+        // per-wave patch (LDS operations of one wave execute in order: no barrier)
+        patch[g * 16 + c16] = dsum;
+        const float S = (patch[c16] + patch[16 + c16]) + (patch[32 + c16] + patch[48 + c16]);
+        if (c_ok)
+            *reinterpret_cast<float4 *>(d.decay + ((int64_t)b * E + c) * 16 + 4 * g) =
+                make_float4(cm_exp2(Ap01.x * S), cm_exp2(Ap01.y * S), cm_exp2(Ap23.x * S), cm_exp2(Ap23.y * S));
     }
 }
 

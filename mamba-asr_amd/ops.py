@@ -323,6 +323,14 @@ def _scan_cl_dir_rows(x, dd, u0, z, keep):
     x.u_bs, x.u_ts, x.out_bs, x.out_ts = u.stride(0), u.stride(1), out.stride(0), out.stride(1)
     x.xdbl_bs, x.xdbl_ts, x.dt_rank = xdbl.stride(0), xdbl.stride(1), 16
     x.reverse_time = int(bool(dd.get("reverse", False)))
+    for key in ("h0", "h_last", "decay"):                    # carry interface of the time-split scan: (batch, dim, 16) fp32
+        t = dd.get(key)
+        if t is not None:
+            _dev_check(t)
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (b, d, 16):
+                raise RuntimeError(f"xdbl mode: {key} must be a contiguous fp32 (batch, dim, 16) tensor")
+            keep.append(t)
+            setattr(x, key, _ptr(t))
     return out
 
 

@@ -237,6 +237,74 @@ def encoder_forward_seq_parallel(encoder, src_shard, group, backend=HipBackend):
     return encoder.norm(out)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# the same, on the channels-last fused inference kernels (the path bench.py times; bf16, d_model 256)
+# ------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def encoder_forward_seq_parallel_fused(encoder, src_shard, group):
+    """Time-split ConmambaEncoder.forward on the FUSED kernels of fused.py (cm_ffn_fused, cm_conv_xproj, the row-group
+    cm_scan_cl_fwd, cm_ln_pw_glu, cm_glu_dwconv_ln_gelu; bf16 GEMM operands, fp32 residual stream).  Row-local kernels run
+    unchanged on the shard; the three time-mixing kernels run on halo-extended rows (3 frames either side for the two
+    causal convs, 15 either side for the k = 31 depthwise conv; the outputs of the halo rows are dropped), and the scan
+    runs twice: from a zero state, writing (decay, h_last) -- cm_scan_cl_dir's carry outputs -- which ONE all-gather per
+    layer spreads, then from the folded carry (h0).  src_shard (batch, T_local, 256) -> (batch, T_local, 256) fp32.
+    Raises if a layer is not covered by the all-native bf16 route (then use encoder_forward_seq_parallel)."""
+    from . import fused, ops
+    dtype = torch.bfloat16
+    batch, T, D = src_shard.shape
+    caches = [fused._cache(layer, dtype) for layer in encoder.layers]
+    for layer, c in zip(encoder.layers, caches):
+        if not (fused.supports(layer) and ops.ffn_supported(D, c.ffn1["w1"].shape[0], dtype) and c.rows_mode and c.wx_packed is not None
+                and c.pw_packed is not None and c.in_bias is None and c.out_bias is None and c.gamma is None):
+            raise NotImplementedError("layer outside the fused bf16 route (d_model 256, dt_rank <= 16): use encoder_forward_seq_parallel")
+    dev = src_shard.device
+    fin = (encoder.norm.norm.weight.detach().float(), encoder.norm.norm.bias.detach().float(), encoder.norm.norm.eps)
+    E = caches[0].d_inner
+    with torch.autocast("cuda", enabled=False):
+        x = src_shard.detach().float().reshape(batch * T, D).contiguous().clone()
+        out = None
+        for li, c in enumerate(caches):
+            f1, f2 = c.ffn1, c.ffn2
+            _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)
+            xz = (h @ c.in_proj.t()).view(batch, T, 2 * E)
+            # both causal convs + x_proj on rows extended by 3 frames either side
+            left, right = exchange_halo(xz[:, :, :E], 3, 3, group, dim=1)
+            xext = torch.cat([left, xz[:, :, :E], right], dim=1)
+            uext = torch.empty((batch, T + 6, 2 * E), dtype=dtype, device=dev)
+            xdbl_ext = ops.conv_xproj(xext, c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
+                                      c.wx_packed[0], c.wx_packed[1], out_f=uext[:, :, :E], out_b=uext[:, :, E:])
+            ucat, xdbl = uext[:, 3:3 + T], xdbl_ext[:, 3:3 + T]
+            ycat = torch.empty((batch, T, 2 * E), dtype=dtype, device=dev)
+            summ = torch.empty((2, 2, batch, E, 16), dtype=torch.float32, device=dev)      # [direction][decay | h_last]
+            dirs = [dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], D=d["D"], delta_bias=d["dt_bias"], dt_weight=d["dt_w16"],
+                         xdbl=xdbl[:, :, 48 * i:48 * (i + 1)], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i),
+                         decay=summ[i, 0], h_last=summ[i, 1]) for i, d in enumerate(c.dirs)]
+            ops.scan_cl_fwd(dirs, z=xz[:, :, E:], delta_softplus=True)                     # pass 1: from a zero state
+            allsum = group.all_gather(summ)
+            redo = []
+            for i in range(2):
+                H = carry_in([s_[i, 0] for s_ in allsum], [s_[i, 1] for s_ in allsum], group.rank, bool(i))
+                if H is not None:
+                    dd = {k: v for k, v in dirs[i].items() if k not in ("decay", "h_last")}
+                    dd["h0"] = H.contiguous()
+                    redo.append(dd)
+            if redo:
+                ops.scan_cl_fwd(redo, z=xz[:, :, E:], delta_softplus=True)                 # pass 2: from the carry
+            y = ycat.view(batch * T, 2 * E) @ c.out_cat.t()
+            gl = ops.ln_pw_glu(x, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
+            gl3 = gl.view(batch, T, D)
+            left, right = exchange_halo(gl3, 15, 15, group, dim=1)
+            g = ops.glu_dwconv_ln_gelu(torch.cat([left, gl3, right], dim=1), c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2],
+                                       weight_t=c.dw_wt, glu_done=True)[:, 15:15 + T]
+            yl = torch.addmm(c.lin_b, g.reshape(-1, D), c.lin_w.t())
+            if li == len(caches) - 1:
+                _, out = ops.ffn_fused(x, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=yl, norm1=c.norm2,
+                                       norm2=fin, h_dtype=torch.float32)
+            else:
+                ops.ffn_fused(x, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=yl, norm1=c.norm2, want_h=False)
+        return out.view(batch, T, D)
+
+
 def exchange_bytes_per_layer(batch: int, d_model: int, expand: int = 2, d_state: int = 16, d_conv: int = 4, kernel_size: int = 31,
                              itemsize: int = 4) -> int:
     """Bytes one rank contributes to the all-gathers of one layer: 2 directions x (P, h_end) fp32 + the three halos."""

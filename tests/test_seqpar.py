@@ -173,3 +173,63 @@ def test_time_split_encoder_on_hip_kernels(world):
     # and against the CPU oracle on the whole sequence
     ref = _unsplit_cpu(enc.cpu(), x.cpu())
     torch.testing.assert_close(torch.cat(got, dim=1).cpu(), ref, rtol=2e-3, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reverse", [False, True])
+def test_row_group_scan_carry_interface(reverse):
+    """cm_scan_cl_fwd (row-group kernel) h0 / h_last / decay: a sequence scanned in two pieces, the second from the first's
+    h_last, equals the whole; decay = exp(A * sum delta'); h_last of the continued piece = h_last of the whole."""
+    from mamba_asr_amd import ops
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(4)
+    b, l, e, cut = 3, 205, 64, 120
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    u, z = rnd(b, l, e).bfloat16(), rnd(b, l, e).bfloat16()
+    xdbl = (rnd(b, l, 48) * 0.5).bfloat16()
+    A = -torch.exp(rnd(e, 16) * 0.3)
+    Wdt = ops.pad_dt_weight(rnd(e, 16) * 0.25)
+    D, bias = torch.ones(e, device=dev), rnd(e) - 2
+    common = dict(A=A, D=D, delta_bias=bias, dt_weight=Wdt, reverse=reverse)
+    st = lambda: torch.empty(b, e, 16, device=dev)
+    hw, dw = st(), st()
+    (whole,) = ops.scan_cl_fwd([dict(common, u=u, xdbl=xdbl, h_last=hw, decay=dw)], z=z)
+    first, second = (slice(cut, l), slice(0, cut)) if reverse else (slice(0, cut), slice(cut, l))
+    cs = lambda t, s: t[:, s].contiguous()
+    h1, d1, h2, d2 = st(), st(), st(), st()
+    (y1,) = ops.scan_cl_fwd([dict(common, u=cs(u, first), xdbl=cs(xdbl, first), h_last=h1, decay=d1)], z=cs(z, first))
+    (y2,) = ops.scan_cl_fwd([dict(common, u=cs(u, second), xdbl=cs(xdbl, second), h0=h1, h_last=h2, decay=d2)], z=cs(z, second))
+    assert torch.equal(y1, whole[:, first]) and torch.equal(y2, whole[:, second])
+    torch.testing.assert_close(h2, hw, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(d1 * d2, dw, rtol=2e-5, atol=1e-30)
+    # decay against its definition, delta' from the bf16 dt columns and the bf16-rounded weight as the kernel forms it
+    dt = xdbl[:, first, :16].float() @ Wdt.bfloat16().float().t() + bias
+    want = torch.exp(A[None] * torch.nn.functional.softplus(dt).sum(1)[:, :, None])
+    torch.testing.assert_close(d1, want, rtol=2e-3, atol=1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_time_split_fused_encoder_vs_reference_golden(world, golden):
+    """The fused bf16 route (the kernels bench.py times) cut into 2 / 4 time shards, against the REFERENCE's 2-layer
+    d_model-256 encoder (golden g4_large: 16 x 100 x 256) and against the unsplit fused route."""
+    import importlib.util
+    from mamba_asr_amd import fused, seqpar
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoder
+    spec = importlib.util.spec_from_file_location("golden_synth", os.path.join(os.path.dirname(__file__), "golden", "synth.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    enc = ConmambaEncoder(num_layers=2, d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True, dropout=0.0,
+                          causal=False, mamba_config=dict(CFG))
+    enc.load_state_dict(S.synth_like(enc, 256), strict=True)
+    enc = enc.to("cuda").eval()
+    x = S.synth_input("g4_large.x", (16, 100, 256), 256).to("cuda")
+    T = x.shape[1] // world
+    got = torch.cat(seqpar.run_local(world, lambda grp: seqpar.encoder_forward_seq_parallel_fused(
+        enc, x[:, grp.rank * T:(grp.rank + 1) * T].contiguous(), grp)), dim=1)
+    torch.testing.assert_close(got.cpu(), golden("g4_large")["y_enc"], rtol=3e-2, atol=5e-2)
+    with torch.no_grad():
+        unsplit = fused.encoder_forward(enc, x, dtype=torch.bfloat16, streams=1)
+    err = (got - unsplit).abs()
+    print(f"time-split fused (W={world}) vs unsplit fused: max|diff| {err.max():.3e} mean {err.mean():.3e}")
+    assert err.mean() < 2e-3 and err.max() < 6e-2          # same kernels; shard edges change bf16 rounding order only
