@@ -215,12 +215,13 @@ typedef struct cm_scan_cl_dir {
     int64_t bc_ns, bc_bs;    /* state / batch strides of B and C                            */
     int32_t reverse_time;
     int32_t dt_rank;
-    const void *xdbl;        /* optional (batch, seqlen, 48) in the I/O dtype: the x_proj GEMM's output rows as it
-                                wrote them, columns [0,16) = dt features zero-padded to 16, [16,32) = B_t, [32,48) =
-                                C_t (selective_scan_interface.py:186, 192-215 without the transposed copies).  When
-                                set for every direction, B / C / dt_low / delta are ignored, dt_weight must be
-                                (dim, 16) fp32 zero-padded, dim a multiple of 8 (bf16) / 4 (fp32), and the row-group
-                                kernel (csrc/scan_rows_fwd.hip) runs                                                */
+    const void *xdbl;        /* optional (batch, seqlen, P + 32) in the I/O dtype: the x_proj GEMM's output rows as it
+                                wrote them, columns [0,P) = dt features zero-padded to P, [P,P+16) = B_t, [P+16,P+32)
+                                = C_t (selective_scan_interface.py:186, 192-215 without the transposed copies), where
+                                P = 16 when dt_rank <= 16 and P = 32 when 16 < dt_rank <= 32 (bf16 only; the S2S-large
+                                encoder, d_model 512).  When set for every direction, B / C / dt_low / delta are
+                                ignored, dt_weight must be (dim, P) fp32 zero-padded, dim a multiple of 8 (bf16) /
+                                4 (fp32), and the row-group kernel (csrc/scan_rows_fwd.hip) runs                    */
     int64_t xdbl_bs, xdbl_ts;/* batch / step strides of xdbl in elements (multiples of 8 for bf16, 4 for fp32)       */
     /* xdbl mode only, all optional, (batch, dim, 16) fp32 contiguous -- the carry interface of the time-split scan
        (no reference counterpart): */

@@ -79,7 +79,9 @@ __device__ __forceinline__ void st_io(const __amdgpu_buffer_rsrc_t r, int voff, 
 // FULL: z gate and softplus present (the BiMamba layer's call), resolved at compile time
 // ABL (timing-only ablations, cm_debug_set): 1 = exp replaced by a multiply-add, 2 = B/C not read from LDS,
 // 3 = no per-(channel,step) owner work (softplus / gate), 4 = plain add instead of the output MFMA, 5 = no staging
-template <typename IO, bool REV, bool FULL, int ABL = 0>
+// DTR: zero-padded dt_rank of the x_dbl rows, 16 or 32 (32: bf16 only; rows are then [dt32 | B16 | C16] and the K = 32 bf16
+// MFMA that forms delta contracts real columns in all four lane groups -- the S2S-large encoder, d_model 512)
+template <typename IO, bool REV, bool FULL, int ABL = 0, int DTR = 16>
 __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, unsigned char *lds,
                                           const int cx, const int b) {
     using L = rows_lds<IO>;
@@ -88,7 +90,10 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     constexpr int CPR = 64 / VEC;                // 16-byte chunks per 64-channel row
     constexpr int NCH = TB * CPR;                // chunks per (u or z) tile
     constexpr int NV = 2 * NCH / 256;            // chunks per thread per block (u and z together)
-    constexpr int XCPR = 48 / VEC;               // chunks per x_dbl row
+    constexpr int RW = DTR + 32;                 // x_dbl row width
+    constexpr int XCPR = RW / VEC;               // chunks per x_dbl row
+    constexpr int DTC = DTR / 8;                 // bf16 I/O: 16-byte chunks of raw dt columns per row
+    static_assert(DTR == 16 || (DTR == 32 && sizeof(IO) == 2), "dt_rank 32 needs bf16 I/O");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
@@ -103,7 +108,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     const __amdgpu_buffer_rsrc_t ur = make_rsrc(reinterpret_cast<const IO *>(d.u) + (int64_t)b * d.u_bs, ((int64_t)(T - 1) * u_ts + E) * S);
     const __amdgpu_buffer_rsrc_t zr = make_rsrc(has_z ? reinterpret_cast<const IO *>(p.z) + (int64_t)b * p.z_bs : nullptr,
                                                 has_z ? ((int64_t)(T - 1) * z_ts + E) * S : 0);
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const IO *>(d.xdbl) + (int64_t)b * d.xdbl_bs, ((int64_t)(T - 1) * x_ts + 48) * S);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const IO *>(d.xdbl) + (int64_t)b * d.xdbl_bs, ((int64_t)(T - 1) * x_ts + RW) * S);
     const __amdgpu_buffer_rsrc_t orr = make_rsrc(reinterpret_cast<IO *>(d.out) + (int64_t)b * d.out_bs, ((int64_t)(T - 1) * o_ts + E) * S);
     const int tb0 = (REV ? nblk - 1 : 0) * TB;               // first block's base step; blocks advance by +-TB steps
     constexpr int DIR = REV ? -1 : 1;
@@ -124,8 +129,9 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     const int x_step = x_thread ? DIR * TB * x_ts * S : 0;
     // bf16 I/O: the dt columns (chunks 0, 1 of a row) stay RAW bf16 in the first 32 bytes of the staged row -- they are
     // the A operand of one bf16 MFMA; B and C (chunks 2..5) are widened to fp32 at floats 16..47 for the recurrence
-    const bool x_raw = S == 2 && tid % XCPR < 2;
-    const int x_lds = L::kX + (tid / XCPR) * XS * 4 + (x_raw ? (tid % XCPR) * 16 : (tid % XCPR) * VEC * 4);
+    const bool x_raw = S == 2 && tid % XCPR < DTC;
+    const int x_lds = L::kX + (tid / XCPR) * XS * 4 +
+                      (x_raw ? (tid % XCPR) * 16 : (S == 2 ? (16 + (tid % XCPR - DTC) * VEC) * 4 : (tid % XCPR) * VEC * 4));
     u32x4 ruz[NV], rx;
     auto issue = [&]() {                                          // next block in processing order
 #pragma unroll
@@ -160,9 +166,9 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         if constexpr (S == 2) {
             // The reference runs this product as a bf16 GEMM under autocast (selective_scan_interface.py:187: weight and
             // x_dbl both cast to bf16, fp32 accumulate); here too, except that delta stays fp32 afterwards.
-            const float *wr = d.dt_weight + (int64_t)cc * 16 + 8 * (g & 1);
+            const float *wr = d.dt_weight + (int64_t)cc * DTR + 8 * (DTR == 32 ? g : (g & 1));
             const float4 lo = *reinterpret_cast<const float4 *>(wr), hi = *reinterpret_cast<const float4 *>(wr + 4);
-            const float sc = g < 2 ? 1.f : 0.f;
+            const float sc = (DTR == 32 || g < 2) ? 1.f : 0.f;
             typedef float f32x8 __attribute__((ext_vector_type(8)));
             Wdt8 = __builtin_convertvector(f32x8{lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc}, bf16x8);
         }
@@ -195,7 +201,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             // ONE v_mfma_f32_16x16x32_bf16 (4 passes) instead of four fp32 MFMAs (8 passes each).  A operand: lane
             // (m = step = lane%16, k block = lane/16) holds dt[step][8k .. 8k+7]; the blocks k = 2, 3 re-read blocks
             // 0, 1 (finite data) against zero weights.
-            const bf16x8 dt8 = *reinterpret_cast<const bf16x8 *>(xt + c16 * XS + 4 * (g & 1));
+            const bf16x8 dt8 = *reinterpret_cast<const bf16x8 *>(xt + c16 * XS + 4 * (DTR == 32 ? g : (g & 1)));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt8, Wdt8, acc, 0, 0, 0);
         } else {
             // A operand: lane (m = step = lane%16, k = lane/16) holds dt[step][4k + q]
@@ -341,7 +347,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     }
 }
 
-template <typename IO, int ABL>
+template <typename IO, int ABL, int DTR = 16>
 __global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_kernel(const cm_scan_cl_args p, const int nx) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[rows_lds<IO>::kBytes];
     // workgroups of one (batch, direction) share x_dbl rows and neighbouring row segments: keep them on one XCD
@@ -353,11 +359,11 @@ __global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_ke
     const cm_scan_cl_dir &d = p.dir[z];
     const bool full = p.z != nullptr && p.delta_softplus != 0;
     if (full) {
-        if (d.reverse_time) scan_rows<IO, true, true, ABL>(p, d, lds, cx, b);
-        else scan_rows<IO, false, true, ABL>(p, d, lds, cx, b);
+        if (d.reverse_time) scan_rows<IO, true, true, ABL, DTR>(p, d, lds, cx, b);
+        else scan_rows<IO, false, true, ABL, DTR>(p, d, lds, cx, b);
     } else if constexpr (ABL == 0) {
-        if (d.reverse_time) scan_rows<IO, true, false>(p, d, lds, cx, b);
-        else scan_rows<IO, false, false>(p, d, lds, cx, b);
+        if (d.reverse_time) scan_rows<IO, true, false, 0, DTR>(p, d, lds, cx, b);
+        else scan_rows<IO, false, false, 0, DTR>(p, d, lds, cx, b);
     }
 }
 
@@ -367,7 +373,11 @@ int launch_rows(const cm_scan_cl_args &a) {
     const long total = (long)nx * a.batch * a.ndir;
     const dim3 grid((unsigned)total), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
-    if constexpr (sizeof(IO) == 2) {                    // ablation builds exist for the bf16 kernel only
+    if constexpr (sizeof(IO) == 2) {
+        if (a.dir[0].dt_rank > 16) {                    // 64-wide rows, dt features padded to 32
+            hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, 32>), grid, block, 0, st, a, nx);
+            return cm_launch_status("cm_scan_cl_fwd(rows, dt_rank 32)");
+        }
         switch (cm_debug_get()) {
             case 1: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 1>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl1");
             case 2: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 2>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl2");
@@ -394,6 +404,10 @@ int cm_scan_rows_fwd(const cm_scan_cl_args &a) {
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];
         CM_REQUIRE(d.u && d.xdbl && d.A && d.dt_weight && d.out, CM_EINVAL, "scan_cl_fwd(xdbl): dir %d has a NULL tensor", i);
+        CM_REQUIRE(d.dt_rank >= 0 && d.dt_rank <= 32 && (d.dt_rank > 16) == (a.dir[0].dt_rank > 16), CM_EUNSUPPORTED,
+                   "scan_cl_fwd(xdbl): dt_rank %d: at most 32, and every direction on the same side of 16", d.dt_rank);
+        CM_REQUIRE(d.dt_rank <= 16 || a.io_dtype == CM_BF16, CM_EUNSUPPORTED,
+                   "scan_cl_fwd(xdbl): dt_rank %d > 16 (64-wide rows) is built for bf16 I/O only", d.dt_rank);
         CM_REQUIRE(cm_aligned(d.u, 16) && d.u_bs % vec == 0 && d.u_ts % vec == 0 && cm_aligned(d.xdbl, 16) &&
                        d.xdbl_bs % vec == 0 && d.xdbl_ts % vec == 0 && cm_aligned(d.A, 16) && cm_aligned(d.dt_weight, 16),
                    CM_EALIGN, "scan_cl_fwd(xdbl): dir %d: u / xdbl / A / dt_weight must be 16-byte aligned, strides multiples of %d", i, vec);

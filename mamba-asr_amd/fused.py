@@ -62,21 +62,24 @@ class _LayerCache:
         xbd[:P, :m.d_inner] = m.x_proj.weight.detach().to(dtype)
         xbd[P:, m.d_inner:] = m.x_proj_b.weight.detach().to(dtype)
         self.x_proj_bd = xbd
-        # row-major variant for cm_scan_cl_fwd's xdbl mode (dt_rank <= 16): output columns per direction are
-        # [dt (zero padded to 16) | B (16) | C (16)], so the scan reads the GEMM's rows as written
+        # row-major variant for cm_scan_cl_fwd's xdbl mode: output columns per direction are
+        # [dt (zero padded to 16, or to 32 in bf16 when 16 < dt_rank <= 32) | B (16) | C (16)], so the scan reads the
+        # GEMM's rows as written
         R, N = self.dt_rank, self.d_state
-        self.rows_mode = R <= 16 and N == 16 and m.d_inner % 8 == 0
+        self.rows_mode = (R <= 16 or (R <= 32 and dtype == torch.bfloat16)) and N == 16 and m.d_inner % 8 == 0
         if self.rows_mode:
-            xr = torch.zeros(96, 2 * m.d_inner, dtype=dtype, device=m.x_proj.weight.device)
+            pad = ops.rows_dt_pad(R)
+            RW = self.row_width = pad + 32
+            xr = torch.zeros(2 * RW, 2 * m.d_inner, dtype=dtype, device=m.x_proj.weight.device)
             for i, xp in enumerate((m.x_proj, m.x_proj_b)):
                 wsrc = xp.weight.detach().to(dtype)
                 cols = slice(i * m.d_inner, (i + 1) * m.d_inner)
-                xr[48 * i:48 * i + R, cols] = wsrc[:R]
-                xr[48 * i + 16:48 * i + 48, cols] = wsrc[R:]
+                xr[RW * i:RW * i + R, cols] = wsrc[:R]
+                xr[RW * i + pad:RW * (i + 1), cols] = wsrc[R:]
             self.x_proj_rows = xr
             # per-direction (48, E) images for cm_conv_xproj (conv + x_proj in one kernel, bf16)
             self.wx_packed = None
-            if dtype == torch.bfloat16 and m.d_inner % 32 == 0 and xr.is_cuda and m.d_conv == 4:
+            if RW == 48 and dtype == torch.bfloat16 and m.d_inner % 32 == 0 and xr.is_cuda and m.d_conv == 4:
                 self.wx_packed = [ops.PackedWeight(xr[48 * i:48 * (i + 1), i * m.d_inner:(i + 1) * m.d_inner].contiguous())
                                   for i in range(2)]
             for d_, dtp in zip(self.dirs, (m.dt_proj, m.dt_proj_b)):
@@ -146,9 +149,10 @@ def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen, xdbl=None):
     rows, P = batch * seqlen, c.dt_rank + 2 * c.d_state
     if c.rows_mode and USE_SCAN_ROWS:
         if xdbl is None:
-            xdbl = (ucat.view(rows, 2 * E) @ c.x_proj_rows.t()).view(batch, seqlen, 96)  # one library GEMM, rows as the scan reads them
+            xdbl = (ucat.view(rows, 2 * E) @ c.x_proj_rows.t()).view(batch, seqlen, 2 * c.row_width)  # one library GEMM, rows as the scan reads them
+        RW = c.row_width
         return [dict(u=ucat[:, :, i * E:(i + 1) * E], A=d["A"], D=d["D"], delta_bias=d["dt_bias"], dt_weight=d["dt_w16"],
-                     xdbl=xdbl[:, :, 48 * i:48 * (i + 1)], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
+                     xdbl=xdbl[:, :, RW * i:RW * (i + 1)], out=ycat[:, :, i * E:(i + 1) * E], reverse=bool(i))
                 for i, d in enumerate(c.dirs)]
     xdblT = c.x_proj_bd @ ucat.view(rows, 2 * E).t()                      # (2P, rows): [dt | B | C] fwd, then bwd
     feat = ops.alloc_bc(2 * P, batch, seqlen, ucat.device)

@@ -292,27 +292,36 @@ def alloc_bc(nrows: int, batch: int, seqlen: int, device) -> torch.Tensor:
     return flat[:n].view(nrows, batch, seqlen)
 
 
+def rows_dt_pad(dt_rank: int) -> int:
+    """Width the dt features are zero-padded to in the x_dbl rows of cm_scan_cl_fwd's xdbl mode: 16, or 32 (bf16 only)."""
+    if not 1 <= dt_rank <= 32:
+        raise RuntimeError(f"the xdbl mode of cm_scan_cl_fwd needs 1 <= dt_rank <= 32 (got {dt_rank})")
+    return 16 if dt_rank <= 16 else 32
+
+
 def pad_dt_weight(dt_weight: torch.Tensor) -> torch.Tensor:
-    """(dim, dt_rank <= 16) -> (dim, 16) fp32, zero padded: the dt_weight layout of cm_scan_cl_fwd's xdbl mode."""
+    """(dim, dt_rank <= 32) -> (dim, 16 | 32) fp32, zero padded: the dt_weight layout of cm_scan_cl_fwd's xdbl mode."""
     d, r = dt_weight.shape
-    if r > 16:
-        raise RuntimeError("the xdbl mode of cm_scan_cl_fwd needs dt_rank <= 16")
-    out = torch.zeros((d, 16), dtype=torch.float32, device=dt_weight.device)
+    out = torch.zeros((d, rows_dt_pad(r)), dtype=torch.float32, device=dt_weight.device)
     out[:, :r] = dt_weight.detach().float()
     return out
 
 
 def _scan_cl_dir_rows(x, dd, u0, z, keep):
-    """One direction descriptor in xdbl mode: x_dbl rows (batch, seqlen, 48) = [dt16 | B16 | C16] in the I/O dtype."""
+    """One direction descriptor in xdbl mode: x_dbl rows (batch, seqlen, P + 32) = [dt P | B16 | C16] in the I/O dtype,
+    P = 16, or 32 (bf16 only) for 16 < dt_rank <= 32."""
     u, xdbl, dt_w = dd["u"], dd["xdbl"], dd["dt_weight"]
     _dev_check(u, xdbl, dt_w, dd["A"])
     _rows_ok(u, "u")
     _rows_ok(xdbl, "xdbl")
     b, l, d = u0.shape
-    if u.shape != (b, l, d) or xdbl.shape != (b, l, 48) or u.dtype != u0.dtype or xdbl.dtype != u0.dtype:
-        raise RuntimeError("xdbl mode: u (batch, seqlen, dim) and xdbl (batch, seqlen, 48) must share shape prefix and dtype")
-    if dt_w.shape != (d, 16):
-        raise RuntimeError("xdbl mode: dt_weight must be (dim, 16), zero padded (ops.pad_dt_weight)")
+    pad = xdbl.shape[-1] - 32
+    if pad not in (16, 32) or (pad == 32 and u0.dtype != torch.bfloat16):
+        raise RuntimeError("xdbl mode: xdbl rows are 48 wide, or 64 wide (dt_rank > 16) in bf16")
+    if u.shape != (b, l, d) or xdbl.shape != (b, l, pad + 32) or u.dtype != u0.dtype or xdbl.dtype != u0.dtype:
+        raise RuntimeError("xdbl mode: u (batch, seqlen, dim) and xdbl (batch, seqlen, 48 | 64) must share shape prefix and dtype")
+    if dt_w.shape != (d, pad):
+        raise RuntimeError(f"xdbl mode: dt_weight must be (dim, {pad}), zero padded (ops.pad_dt_weight)")
     A, D, bias, dt_w = _f32c(dd["A"]), _f32c(dd.get("D")), _f32c(dd.get("delta_bias")), _f32c(dt_w)
     out = dd.get("out")
     if out is None:
@@ -321,7 +330,7 @@ def _scan_cl_dir_rows(x, dd, u0, z, keep):
     keep += [A, D, bias, dt_w]
     x.u, x.A, x.D, x.delta_bias, x.out, x.dt_weight, x.xdbl = _ptr(u), _ptr(A), _ptr(D), _ptr(bias), _ptr(out), _ptr(dt_w), _ptr(xdbl)
     x.u_bs, x.u_ts, x.out_bs, x.out_ts = u.stride(0), u.stride(1), out.stride(0), out.stride(1)
-    x.xdbl_bs, x.xdbl_ts, x.dt_rank = xdbl.stride(0), xdbl.stride(1), 16
+    x.xdbl_bs, x.xdbl_ts, x.dt_rank = xdbl.stride(0), xdbl.stride(1), pad
     x.reverse_time = int(bool(dd.get("reverse", False)))
     for key in ("h0", "h_last", "decay"):                    # carry interface of the time-split scan: (batch, dim, 16) fp32
         t = dd.get(key)

@@ -238,32 +238,41 @@ def test_scan_channels_last_in_kernel_dt_proj(ops, rank):
 
 @pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 64), (2, 5, 72), (1, 16, 512), (2, 333, 512)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rank", [9, 16])
+@pytest.mark.parametrize("rank", [9, 16, 24, 32])
 def test_scan_rows_two_directions(ops, shape, dtype, rank):
-    """cm_scan_cl_fwd in xdbl mode (row-group kernel, csrc/scan_rows_fwd.hip): x_proj output rows [dt16 | B | C] read
-    as written, delta formed in-kernel on the matrix pipe, both directions in one launch — against the fp64 oracle on
-    the same (dtype-rounded) inputs.  Ragged sizes: seqlen not a multiple of 16, dim not a multiple of 64."""
+    """cm_scan_cl_fwd in xdbl mode (row-group kernel, csrc/scan_rows_fwd.hip): x_proj output rows [dt16 | B | C]
+    (dt_rank <= 16) or [dt32 | B | C] (dt_rank <= 32, bf16: the S2S-large encoder's rank) read as written, delta
+    formed in-kernel on the matrix pipe, both directions in one launch — against the fp64 oracle on the same
+    (dtype-rounded) inputs.  Ragged sizes: seqlen not a multiple of 16, dim not a multiple of 64."""
     b, l, e = shape
+    P = 16 if rank <= 16 else 32                                        # width the dt features are zero-padded to
+    RW = P + 32
+    if P == 32 and dtype == torch.float32:
+        u = torch.zeros(1, 16, 64, device=DEV)
+        with pytest.raises(RuntimeError, match="64 wide"):
+            ops.scan_cl_fwd([dict(u=u, A=-torch.ones(64, 16, device=DEV), dt_weight=torch.zeros(64, 32, device=DEV),
+                                  xdbl=torch.zeros(1, 16, 64, device=DEV))])
+        return
     gen = torch.Generator().manual_seed(l * 11 + e + rank)
     xz = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
     z = xz[:, :, e:]
     dirs, refs = [], []
     ycat = torch.zeros(b, l, 2 * e, dtype=dtype, device=DEV)
-    xcat = torch.zeros(b, l, 96, dtype=dtype)
+    xcat = torch.zeros(b, l, 2 * RW, dtype=dtype)
     for i, rev in enumerate((False, True)):
         u = torch.randn(b, l, e, generator=gen).to(dtype)
         A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
-        xd = torch.randn(b, l, 48, generator=gen)
-        xd[:, :, rank:16] = 0.0
-        xcat[:, :, 48 * i:48 * (i + 1)] = xd.to(dtype)
-        xd = xcat[:, :, 48 * i:48 * (i + 1)].float()                     # what the kernel sees
+        xd = torch.randn(b, l, RW, generator=gen)
+        xd[:, :, rank:P] = 0.0
+        xcat[:, :, RW * i:RW * (i + 1)] = xd.to(dtype)
+        xd = xcat[:, :, RW * i:RW * (i + 1)].float()                     # what the kernel sees
         Wdt = torch.randn(e, rank, generator=gen) * 0.3
         D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
         # bf16 I/O: the kernel runs the dt_proj product as a bf16 MFMA (weight rounded to bf16, fp32 accumulate), which is
         # what the reference does under autocast (selective_scan_interface.py:187); the oracle sees the same rounded weight
         Wq = Wdt.to(dtype).float()
         delta = torch.einsum("er,blr->bel", Wq.double(), xd[:, :, :rank].double())         # (b, e, l), pre-bias
-        Bm, Cm = xd[:, :, 16:32].transpose(1, 2), xd[:, :, 32:48].transpose(1, 2)          # (b, 16, l)
+        Bm, Cm = xd[:, :, P:P + 16].transpose(1, 2), xd[:, :, P + 16:].transpose(1, 2)        # (b, 16, l)
         f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
         tr = lambda t: t.float().transpose(1, 2)
         ref = O.selective_scan(f(tr(u)), f(delta), A, f(Bm), f(Cm), D, f(tr(z)), bias, True, work_dtype=torch.float64)
@@ -272,7 +281,7 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
                          out=ycat[:, :, i * e:(i + 1) * e], reverse=rev))
     gx = xcat.to(DEV)
     for i in range(2):
-        dirs[i]["xdbl"] = gx[:, :, 48 * i:48 * (i + 1)]
+        dirs[i]["xdbl"] = gx[:, :, RW * i:RW * (i + 1)]
     ops.scan_cl_fwd(dirs, z=xz.to(DEV)[:, :, e:], delta_softplus=True)
     tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
     close(ycat[:, :, :e].float(), refs[0], *tol)
@@ -282,11 +291,11 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     # single direction, no z, no D, no bias, no softplus
     (got,) = ops.scan_cl_fwd([dict(u=dirs[0]["u"], A=dirs[0]["A"], dt_weight=dirs[0]["dt_weight"], xdbl=dirs[0]["xdbl"])],
                              delta_softplus=False)
-    xd = xcat[:, :, :48].float()
+    xd = xcat[:, :, :RW].float()
     Wp = dirs[0]["dt_weight"].cpu().to(dtype).float()
-    delta = torch.einsum("er,blr->bel", Wp.double(), xd[:, :, :16].double())
-    ref = O.selective_scan(dirs[0]["u"].cpu().float().transpose(1, 2), delta, dirs[0]["A"].cpu(), xd[:, :, 16:32].transpose(1, 2),
-                           xd[:, :, 32:48].transpose(1, 2), None, None, None, False, work_dtype=torch.float64)
+    delta = torch.einsum("er,blr->bel", Wp.double(), xd[:, :, :P].double())
+    ref = O.selective_scan(dirs[0]["u"].cpu().float().transpose(1, 2), delta, dirs[0]["A"].cpu(), xd[:, :, P:P + 16].transpose(1, 2),
+                           xd[:, :, P + 16:].transpose(1, 2), None, None, None, False, work_dtype=torch.float64)
     close(got.float(), ref.transpose(1, 2), *((2e-3, 1e-4) if dtype == torch.float32 else (1.6e-2, 2e-2)))   # growing states: looser rtol
 
 
