@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 4
+#define CM_ABI_VERSION 5
 
 /* error codes */
 #define CM_OK            0
@@ -236,14 +236,25 @@ typedef struct cm_scan_cl_args {
     int32_t io_dtype;        /* CM_BF16 or CM_F32: u, delta, z, out                         */
     int32_t delta_softplus;
     int32_t ndir;            /* 1 or 2                                                      */
-    int32_t pad_;
+    int32_t time_chunks;     /* xdbl mode only: 0 / 1 = one workgroup per (sequence, 64 channels); C > 1 = cut every
+                                sequence into C chunks of whole 16-step blocks that run in parallel -- a summary pass
+                                (per-chunk decay product and zero-state end state), a carry fold in scan order, and an
+                                output pass from each chunk's entry state: SURVEY.md §8f row 3's algebra inside one
+                                GPU, for batches too small to fill the chip (cm_scan_cl_fwd_auto_chunks).  Outputs
+                                differ from the unchunked launch by fp32 rounding only.  Needs `workspace`.           */
     const void *z;           /* (batch, seqlen, dim) or NULL                                */
     int64_t z_bs, z_ts;
     cm_scan_cl_dir dir[2];
     void *stream;
+    void   *workspace;       /* time_chunks > 1: cm_scan_cl_fwd_workspace_bytes(args) bytes, 16-byte aligned, caller owned */
+    int64_t workspace_bytes;
 } cm_scan_cl_args;
 
 int cm_scan_cl_fwd(const cm_scan_cl_args *args);
+/* bytes of workspace the launch described by args needs (0 unless time_chunks > 1) */
+int64_t cm_scan_cl_fwd_workspace_bytes(const cm_scan_cl_args *args);
+/* the chunk count that fills 256 CUs for this problem size (1 = do not chunk); a pure function of the sizes */
+int32_t cm_scan_cl_fwd_auto_chunks(int32_t batch, int32_t seqlen, int32_t dim, int32_t ndir);
 
 /* ---------------------------------------------------------------------------------------
  * Channels-last causal conv, both BiMamba directions in one pass over x.

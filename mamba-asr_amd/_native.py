@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -68,10 +68,11 @@ class ScanClDir(C.Structure):
 class ScanClArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32),
-        ("io_dtype", i32), ("delta_softplus", i32), ("ndir", i32), ("pad_", i32),
+        ("io_dtype", i32), ("delta_softplus", i32), ("ndir", i32), ("time_chunks", i32),
         ("z", vp), ("z_bs", i64), ("z_ts", i64),
         ("dir", ScanClDir * 2),
         ("stream", vp),
+        ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -232,6 +233,8 @@ SYMBOLS = [
     ("cm_debug_set", C.c_int, [C.c_int]),
     ("cm_debug_get", C.c_int, []),
     ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
+    ("cm_scan_cl_fwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClArgs)]),
+    ("cm_scan_cl_fwd_auto_chunks", i32, [i32, i32, i32, i32]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),

@@ -421,6 +421,7 @@ extern "C" int cm_scan_cl_fwd(const cm_scan_cl_args *args) {
         CM_REQUIRE(with_rows == 0 || with_rows == a.ndir, CM_EINVAL, "scan_cl_fwd: xdbl must be set for every direction or none");
         if (with_rows) return cm_scan_rows_fwd(a);
     }
+    CM_REQUIRE(a.time_chunks <= 1, CM_EUNSUPPORTED, "scan_cl_fwd: time_chunks is built for the xdbl mode only");
     CM_REQUIRE(a.batch <= 65535, CM_EINVAL, "scan_cl_fwd: batch %d exceeds the grid limit", a.batch);
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];

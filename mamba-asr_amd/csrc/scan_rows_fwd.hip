@@ -76,14 +76,31 @@ __device__ __forceinline__ void st_io(const __amdgpu_buffer_rsrc_t r, int voff, 
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
+// How a launch covers the time axis.  chunks == 1: one workgroup runs a whole sequence.  chunks > 1 (small batches: too few
+// (sequence, 64-channel group) pairs to fill 1024 SIMDs): sequences are cut into chunks of chunk_len steps and the launch
+// becomes three -- pass 1 runs the recurrence of every chunk from a zero state and keeps only its summary (decay product,
+// end state), rows_carry_kernel folds the summaries in scan order into each chunk's entry state
+// (H_k = decay_{k-1} H_{k-1} + end_{k-1}), pass 2 runs every chunk again from its entry state and writes the outputs.
+// It is the algebra of the time-split scan across GPUs (seqpar.py) applied inside one.
+struct rows_plan {
+    int nx;                  // 64-channel groups
+    int chunks, chunk_len;   // chunk_len is a multiple of TB
+    int pass;                // 0: single pass, 1: summaries, 2: outputs from carried-in states
+    int need_last;           // pass 1 also runs the last chunk in scan order (the caller asked for h_last / decay)
+    float *h0, *hl, *dc;     // workspace, each (ndir, batch, chunks, dim, 16) fp32
+};
+
 // FULL: z gate and softplus present (the BiMamba layer's call), resolved at compile time
+// SUM: summary pass of a chunked launch -- no output contraction, gate, z or stores
 // ABL (timing-only ablations, cm_debug_set): 1 = exp replaced by a multiply-add, 2 = B/C not read from LDS,
 // 3 = no per-(channel,step) owner work (softplus / gate), 4 = plain add instead of the output MFMA, 5 = no staging
 // DTR: zero-padded dt_rank of the x_dbl rows, 16 or 32 (32: bf16 only; rows are then [dt32 | B16 | C16] and the K = 32 bf16
 // MFMA that forms delta contracts real columns in all four lane groups -- the S2S-large encoder, d_model 512)
-template <typename IO, bool REV, bool FULL, int ABL = 0, int DTR = 16>
+// Runs steps [t_lo, t_lo + T) of sequence b; h0 / h_last / decay point at this run's (dim, 16) carry slabs or are NULL.
+template <typename IO, bool REV, bool FULL, int ABL = 0, int DTR = 16, bool SUM = false>
 __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_scan_cl_dir &d, unsigned char *lds,
-                                          const int cx, const int b) {
+                                          const int cx, const int b, const int t_lo, const int T,
+                                          const float *h0, float *h_last, float *decay) {
     using L = rows_lds<IO>;
     constexpr int S = (int)sizeof(IO);
     constexpr int VEC = cm_elem<IO>::kVec;       // elements per 16-byte vector
@@ -97,19 +114,22 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int T = p.seqlen, E = p.dim, c0 = cx * 64;
+    const int E = p.dim, c0 = cx * 64;
     const int c = c0 + 16 * w + c16;
     const bool c_ok = c < E;
     const int cc = c_ok ? c : E - 1;
-    const bool has_z = FULL || p.z != nullptr;
+    const bool has_z = !SUM && (FULL || p.z != nullptr);
     const bool softplus = FULL || p.delta_softplus != 0;
     const int nblk = (T + TB - 1) / TB;
     const int u_ts = (int)d.u_ts, z_ts = (int)p.z_ts, x_ts = (int)d.xdbl_ts, o_ts = (int)d.out_ts;
-    const __amdgpu_buffer_rsrc_t ur = make_rsrc(reinterpret_cast<const IO *>(d.u) + (int64_t)b * d.u_bs, ((int64_t)(T - 1) * u_ts + E) * S);
-    const __amdgpu_buffer_rsrc_t zr = make_rsrc(has_z ? reinterpret_cast<const IO *>(p.z) + (int64_t)b * p.z_bs : nullptr,
+    const __amdgpu_buffer_rsrc_t ur = make_rsrc(reinterpret_cast<const IO *>(d.u) + (int64_t)b * d.u_bs + (int64_t)t_lo * u_ts,
+                                                ((int64_t)(T - 1) * u_ts + E) * S);
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(has_z ? reinterpret_cast<const IO *>(p.z) + (int64_t)b * p.z_bs + (int64_t)t_lo * z_ts : nullptr,
                                                 has_z ? ((int64_t)(T - 1) * z_ts + E) * S : 0);
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const IO *>(d.xdbl) + (int64_t)b * d.xdbl_bs, ((int64_t)(T - 1) * x_ts + RW) * S);
-    const __amdgpu_buffer_rsrc_t orr = make_rsrc(reinterpret_cast<IO *>(d.out) + (int64_t)b * d.out_bs, ((int64_t)(T - 1) * o_ts + E) * S);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const IO *>(d.xdbl) + (int64_t)b * d.xdbl_bs + (int64_t)t_lo * x_ts,
+                                                ((int64_t)(T - 1) * x_ts + RW) * S);
+    const __amdgpu_buffer_rsrc_t orr = make_rsrc(SUM ? nullptr : reinterpret_cast<IO *>(d.out) + (int64_t)b * d.out_bs + (int64_t)t_lo * o_ts,
+                                                 SUM ? 0 : ((int64_t)(T - 1) * o_ts + E) * S);
     const int tb0 = (REV ? nblk - 1 : 0) * TB;               // first block's base step; blocks advance by +-TB steps
     constexpr int DIR = REV ? -1 : 1;
 
@@ -145,7 +165,10 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     };
     auto commit = [&](const int buf_tile, const int buf_x) {      // byte offsets of the destination tiles
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4 *>(lds + uz_lds[i] + buf_tile) = ruz[i];
+        for (int i = 0; i < NV; ++i) {
+            const int tens = (w * 64 + 256 * i) / NCH;
+            if (tens == 0 || has_z) *reinterpret_cast<u32x4 *>(lds + uz_lds[i] + buf_tile) = ruz[i];
+        }
         if (x_thread) {
             if (x_raw) *reinterpret_cast<u32x4 *>(lds + x_lds + buf_x) = rx;
             else unpack_store(reinterpret_cast<float *>(lds + x_lds + buf_x), uint4{rx[0], rx[1], rx[2], rx[3]}, IO{});
@@ -173,8 +196,8 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             Wdt8 = __builtin_convertvector(f32x8{lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc}, bf16x8);
         }
     }
-    if (d.h0) {                                                   // carry of a time-split scan (seqpar.py), else zero
-        const float4 h4 = *reinterpret_cast<const float4 *>(d.h0 + ((int64_t)b * E + cc) * 16 + 4 * g);
+    if (h0) {                                                     // carry of a time-split scan (seqpar.py / chunked launch), else zero
+        const float4 h4 = *reinterpret_cast<const float4 *>(h0 + (int64_t)cc * 16 + 4 * g);
         h01 = f32x2{h4.x, h4.y};
         h23 = f32x2{h4.z, h4.w};
     }
@@ -249,7 +272,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             if constexpr (ABL == 2) { o.B = f32x4{o.dw.x, o.dw.y, o.dw.x, o.dw.y}; o.C = o.B; }
             else {
                 o.B = *reinterpret_cast<const f32x4 *>(xt + j * XS + 16);
-                o.C = *reinterpret_cast<const f32x4 *>(xt + j * XS + 32);
+                if constexpr (!SUM) o.C = *reinterpret_cast<const f32x4 *>(xt + j * XS + 32);
             }
         };
         float part[TB];                                           // this lane's 4-state partial outputs, by step
@@ -263,9 +286,11 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             const f32x2 b01 = du2 * f32x2{o.B[0], o.B[1]}, b23 = du2 * f32x2{o.B[2], o.B[3]};
             h01 = __builtin_elementwise_fma(a01, h01, b01);
             h23 = __builtin_elementwise_fma(a23, h23, b23);
-            f32x2 p2 = f32x2{o.C[0], o.C[1]} * h01;
-            p2 = __builtin_elementwise_fma(f32x2{o.C[2], o.C[3]}, h23, p2);
-            part[slot(sp)] = p2.x + p2.y;
+            if constexpr (!SUM) {
+                f32x2 p2 = f32x2{o.C[0], o.C[1]} * h01;
+                p2 = __builtin_elementwise_fma(f32x2{o.C[2], o.C[3]}, h23, p2);
+                part[slot(sp)] = p2.x + p2.y;
+            }
         };
         StepOps q[2][2];
         fetch(0, q[0][0]);
@@ -280,9 +305,11 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             step(2 * sg + 1, q[sg & 1][1]);
             // pin the state here: machine-sink otherwise moves the whole h chain below the last scheduling barrier
             // (its results are only consumed at the end of the block) and keeps 64 exp results alive instead
-            asm volatile("" : "+v"(h01), "+v"(h23), "+v"(part[slot(2 * sg)]), "+v"(part[slot(2 * sg + 1)]));
+            if constexpr (SUM) asm volatile("" : "+v"(h01), "+v"(h23));
+            else asm volatile("" : "+v"(h01), "+v"(h23), "+v"(part[slot(2 * sg)]), "+v"(part[slot(2 * sg + 1)]));
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (SUM) return f32x4{0.f, 0.f, 0.f, 0.f};
         // sum over the 4 lane groups through the per-wave patch (the (delta', delta'*u) patch is dead by now; LDS
         // operations of one wave execute in order, so no barrier): afterwards lane (c, g) holds y of steps 4g..4g+3.
         // (An MFMA with a one-hot A operand per step did this too, but v_mfma_f32_16x16x4_f32 holds the SIMD for 8
@@ -324,7 +351,7 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         const bool more = ABL != 5 && k + 2 < nblk;
         if (more) issue();
         const f32x4 y = recur(x_cur);
-        gate(y);
+        if constexpr (!SUM) gate(y);
         tb += DIR * TB;
         if (k + 1 < nblk) produce(t_nxt, x_nxt, tb);
         if (more) commit(t_fill, x_fill);
@@ -334,64 +361,165 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
         x_cur = x_nxt; x_nxt = x_fill; x_fill = x_old;
     }
     // ---- carry outputs of a time shard: last state, and the factor a state entering the shard is multiplied by
-    if (d.h_last && c_ok)
-        *reinterpret_cast<float4 *>(d.h_last + ((int64_t)b * E + c) * 16 + 4 * g) = make_float4(h01.x, h01.y, h23.x, h23.y);
-    if (d.decay) {
+    if (h_last && c_ok)
+        *reinterpret_cast<float4 *>(h_last + (int64_t)c * 16 + 4 * g) = make_float4(h01.x, h01.y, h23.x, h23.y);
+    if (decay) {
         // sum of delta' over the sequence for channel c16: this lane's owned steps + the other three lane groups', through the
         // per-wave patch (LDS operations of one wave execute in order: no barrier)
         patch[g * 16 + c16] = dsum;
         const float S = (patch[c16] + patch[16 + c16]) + (patch[32 + c16] + patch[48 + c16]);
         if (c_ok)
-            *reinterpret_cast<float4 *>(d.decay + ((int64_t)b * E + c) * 16 + 4 * g) =
+            *reinterpret_cast<float4 *>(decay + (int64_t)c * 16 + 4 * g) =
                 make_float4(cm_exp2(Ap01.x * S), cm_exp2(Ap01.y * S), cm_exp2(Ap23.x * S), cm_exp2(Ap23.y * S));
     }
 }
 
-template <typename IO, int ABL, int DTR = 16>
-__global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_kernel(const cm_scan_cl_args p, const int nx) {
+template <typename IO, int ABL, int DTR = 16, bool SUM = false>
+__global__ __launch_bounds__(256, sizeof(IO) == 2 ? 4 : 3) void scan_rows_fwd_kernel(const cm_scan_cl_args p, const rows_plan pl) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[rows_lds<IO>::kBytes];
     // workgroups of one (batch, direction) share x_dbl rows and neighbouring row segments: keep them on one XCD
     // (consecutive workgroup ids are dealt round-robin to the 8 XCDs)
-    const int total = gridDim.x;
+    const int total = gridDim.x, nx = pl.nx, nbk = p.batch * pl.chunks;
     int id = blockIdx.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
-    const int cx = id % nx, b = (id / nx) % p.batch, z = id / (nx * p.batch);
+    const int cx = id % nx, bk = (id / nx) % nbk, z = id / (nx * nbk);
+    const int b = bk / pl.chunks, k = bk % pl.chunks;
     const cm_scan_cl_dir &d = p.dir[z];
+    const int t_lo = k * pl.chunk_len, T = min(p.seqlen - t_lo, pl.chunk_len);
+    const float *h0;
+    float *h_last, *decay;
+    if (pl.pass == 0) {
+        const int64_t slab = (int64_t)b * p.dim * 16;
+        h0 = d.h0 ? d.h0 + slab : nullptr;
+        h_last = d.h_last ? d.h_last + slab : nullptr;
+        decay = d.decay ? d.decay + slab : nullptr;
+    } else {
+        const int64_t slab = (((int64_t)z * p.batch + b) * pl.chunks + k) * p.dim * 16;
+        if (SUM) {
+            // the last chunk in scan order hands nothing on
+            if (!pl.need_last && k == (d.reverse_time ? 0 : pl.chunks - 1)) return;
+            h0 = nullptr, h_last = pl.hl + slab, decay = pl.dc + slab;
+        } else {
+            h0 = pl.h0 + slab, h_last = nullptr, decay = nullptr;
+        }
+    }
     const bool full = p.z != nullptr && p.delta_softplus != 0;
     if (full) {
-        if (d.reverse_time) scan_rows<IO, true, true, ABL, DTR>(p, d, lds, cx, b);
-        else scan_rows<IO, false, true, ABL, DTR>(p, d, lds, cx, b);
+        if (d.reverse_time) scan_rows<IO, true, true, ABL, DTR, SUM>(p, d, lds, cx, b, t_lo, T, h0, h_last, decay);
+        else scan_rows<IO, false, true, ABL, DTR, SUM>(p, d, lds, cx, b, t_lo, T, h0, h_last, decay);
     } else if constexpr (ABL == 0) {
-        if (d.reverse_time) scan_rows<IO, true, false, 0, DTR>(p, d, lds, cx, b);
-        else scan_rows<IO, false, false, 0, DTR>(p, d, lds, cx, b);
+        if (d.reverse_time) scan_rows<IO, true, false, 0, DTR, SUM>(p, d, lds, cx, b, t_lo, T, h0, h_last, decay);
+        else scan_rows<IO, false, false, 0, DTR, SUM>(p, d, lds, cx, b, t_lo, T, h0, h_last, decay);
     }
+}
+
+// Entry state of every chunk from the chunk summaries, in scan order; the caller's h0 enters the first chunk, the caller's
+// h_last / decay (whole-sequence values) leave the last.  One thread per (direction, sequence, channel, 4 states).
+__global__ __launch_bounds__(256) void rows_carry_kernel(const cm_scan_cl_args p, const rows_plan pl) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int E = p.dim, C = pl.chunks;
+    if (idx >= (int64_t)p.ndir * p.batch * E * 4) return;
+    const int q = (int)(idx & 3), c = (int)((idx >> 2) % E), b = (int)((idx >> 2) / E % p.batch), z = (int)((idx >> 2) / E / p.batch);
+    const cm_scan_cl_dir &d = p.dir[z];
+    const int64_t user = ((int64_t)b * E + c) * 16 + 4 * q;
+    float4 H = d.h0 ? *reinterpret_cast<const float4 *>(d.h0 + user) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 P = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (int i = 0; i < C; ++i) {
+        const int k = d.reverse_time ? C - 1 - i : i;
+        const int64_t off = ((((int64_t)z * p.batch + b) * C + k) * E + c) * 16 + 4 * q;
+        *reinterpret_cast<float4 *>(pl.h0 + off) = H;
+        if (i + 1 < C || pl.need_last) {
+            const float4 a = *reinterpret_cast<const float4 *>(pl.dc + off), e = *reinterpret_cast<const float4 *>(pl.hl + off);
+            H = make_float4(fmaf(a.x, H.x, e.x), fmaf(a.y, H.y, e.y), fmaf(a.z, H.z, e.z), fmaf(a.w, H.w, e.w));
+            P = make_float4(P.x * a.x, P.y * a.y, P.z * a.z, P.w * a.w);
+        }
+    }
+    if (d.h_last) *reinterpret_cast<float4 *>(d.h_last + user) = H;
+    if (d.decay) *reinterpret_cast<float4 *>(d.decay + user) = P;
+}
+
+// chunk length for a requested chunk count: whole 16-step blocks, so only a sequence's last chunk is ragged
+inline int rows_chunk_len(int seqlen, int chunks) { return ((seqlen + chunks - 1) / chunks + TB - 1) / TB * TB; }
+
+template <typename IO, int DTR>
+int launch_rows_chunked(const cm_scan_cl_args &a, rows_plan pl) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    const dim3 grid((unsigned)((long)pl.nx * a.batch * pl.chunks * a.ndir)), block(256);
+    pl.pass = 1;
+    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, DTR, true>), grid, block, 0, st, a, pl);
+    if (int rc = cm_launch_status("cm_scan_cl_fwd(rows, chunk summaries)")) return rc;
+    const long nthr = (long)a.ndir * a.batch * a.dim * 4;
+    hipLaunchKernelGGL(rows_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), block, 0, st, a, pl);
+    if (int rc = cm_launch_status("cm_scan_cl_fwd(rows, carry)")) return rc;
+    pl.pass = 2;
+    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, DTR, false>), grid, block, 0, st, a, pl);
+    return cm_launch_status("cm_scan_cl_fwd(rows, chunked)");
 }
 
 template <typename IO>
 int launch_rows(const cm_scan_cl_args &a) {
-    const int nx = (a.dim + 63) / 64;
-    const long total = (long)nx * a.batch * a.ndir;
+    rows_plan pl{};
+    pl.nx = (a.dim + 63) / 64;
+    pl.chunks = 1;
+    pl.chunk_len = (a.seqlen + TB - 1) / TB * TB;
+    if (a.time_chunks > 1) {
+        pl.chunk_len = rows_chunk_len(a.seqlen, a.time_chunks);
+        pl.chunks = (a.seqlen + pl.chunk_len - 1) / pl.chunk_len;
+    }
+    if (pl.chunks > 1) {
+        const int64_t slab = (int64_t)a.ndir * a.batch * pl.chunks * a.dim * 16;
+        pl.h0 = reinterpret_cast<float *>(a.workspace);
+        pl.hl = pl.h0 + slab;
+        pl.dc = pl.hl + slab;
+        for (int i = 0; i < a.ndir; ++i) pl.need_last |= a.dir[i].h_last != nullptr || a.dir[i].decay != nullptr;
+        if constexpr (sizeof(IO) == 2) {
+            if (a.dir[0].dt_rank > 16) return launch_rows_chunked<IO, 32>(a, pl);
+        }
+        return launch_rows_chunked<IO, 16>(a, pl);
+    }
+    const long total = (long)pl.nx * a.batch * a.ndir;
     const dim3 grid((unsigned)total), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     if constexpr (sizeof(IO) == 2) {
         if (a.dir[0].dt_rank > 16) {                    // 64-wide rows, dt features padded to 32
-            hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, 32>), grid, block, 0, st, a, nx);
+            hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, 32>), grid, block, 0, st, a, pl);
             return cm_launch_status("cm_scan_cl_fwd(rows, dt_rank 32)");
         }
-        switch (cm_debug_get()) {
-            case 1: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 1>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl1");
-            case 2: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 2>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl2");
-            case 3: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 3>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl3");
-            case 4: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 4>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl4");
-            case 5: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 5>), grid, block, 0, st, a, nx); return cm_launch_status("rows abl5");
+        switch (cm_debug_get()) {                       // ablation builds exist for the bf16 kernel only
+            case 1: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 1>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl1");
+            case 2: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 2>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl2");
+            case 3: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 3>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl3");
+            case 4: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 4>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl4");
+            case 5: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 5>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl5");
             default: break;
         }
     }
-    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0>), grid, block, 0, st, a, nx);
+    hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0>), grid, block, 0, st, a, pl);
     return cm_launch_status("cm_scan_cl_fwd(rows)");
 }
 
 }  // namespace
+
+extern "C" int64_t cm_scan_cl_fwd_workspace_bytes(const cm_scan_cl_args *a) {
+    if (!a || a->time_chunks <= 1 || a->seqlen <= 0) return 0;
+    const int len = rows_chunk_len(a->seqlen, a->time_chunks);
+    const int64_t chunks = (a->seqlen + len - 1) / len;
+    return chunks > 1 ? 3 * (int64_t)a->ndir * a->batch * chunks * a->dim * 16 * (int64_t)sizeof(float) : 0;
+}
+
+// Chunk count that fills the chip.  Chunking runs the recurrence twice (the summary pass keeps 56 of the 68 issue cycles of a
+// step: the four exponentials stay), so it pays only while compute units sit idle: measured on MI355X (tools/
+// bench_scan_chunks.py, profiles/r02/scan_time_chunks.log) 8 x 1000 x 512 97 -> 68 us, 4 x 4000 x 1024 378 -> 215 us,
+// 1 x 4000 x 512 376 -> 61 us, but 16 x 1000 x 512 (one workgroup per CU already) 106 -> 112-116 us.  Below 256 workgroups the
+// sequences are cut so that (64-channel groups) x batch x directions x chunks reaches 1024, chunks no shorter than 128 steps.
+extern "C" int32_t cm_scan_cl_fwd_auto_chunks(int32_t batch, int32_t seqlen, int32_t dim, int32_t ndir) {
+    if (batch <= 0 || seqlen <= 0 || dim <= 0 || ndir <= 0) return 1;
+    const long wgs = (long)((dim + 63) / 64) * batch * ndir;
+    if (wgs >= 256) return 1;
+    long c = 1024 / wgs;
+    if (c > seqlen / 128) c = seqlen / 128;
+    return c < 2 ? 1 : (int32_t)c;
+}
 
 // called by cm_scan_cl_fwd (scan_cl_fwd.hip) when every direction carries xdbl
 int cm_scan_rows_fwd(const cm_scan_cl_args &a) {
@@ -400,7 +528,15 @@ int cm_scan_rows_fwd(const cm_scan_cl_args &a) {
     CM_REQUIRE(a.dim % vec == 0, CM_EUNSUPPORTED, "scan_cl_fwd(xdbl): dim %d must be a multiple of %d", a.dim, vec);
     CM_REQUIRE(!a.z || (cm_aligned(a.z, 16) && a.z_bs % vec == 0 && a.z_ts % vec == 0), CM_EALIGN,
                "scan_cl_fwd(xdbl): z must be 16-byte aligned with strides that are multiples of %d", vec);
-    CM_REQUIRE((long)((a.dim + 63) / 64) * a.batch * a.ndir < (1L << 31), CM_EINVAL, "scan_cl_fwd(xdbl): grid too large");
+    CM_REQUIRE(a.time_chunks >= 0 && a.time_chunks <= 4096, CM_EINVAL, "scan_cl_fwd(xdbl): time_chunks %d out of range", a.time_chunks);
+    const int chunks = a.time_chunks > 1 ? (a.seqlen + rows_chunk_len(a.seqlen, a.time_chunks) - 1) / rows_chunk_len(a.seqlen, a.time_chunks) : 1;
+    CM_REQUIRE((long)((a.dim + 63) / 64) * a.batch * a.ndir * chunks < (1L << 31), CM_EINVAL, "scan_cl_fwd(xdbl): grid too large");
+    if (chunks > 1) {
+        const int64_t need = cm_scan_cl_fwd_workspace_bytes(&a);
+        CM_REQUIRE(a.workspace && cm_aligned(a.workspace, 16) && a.workspace_bytes >= need, CM_EINVAL,
+                   "scan_cl_fwd(xdbl): time_chunks %d needs a 16-byte aligned workspace of %lld bytes (cm_scan_cl_fwd_workspace_bytes), got %lld",
+                   a.time_chunks, (long long)need, (long long)a.workspace_bytes);
+    }
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_dir &d = a.dir[i];
         CM_REQUIRE(d.u && d.xdbl && d.A && d.dt_weight && d.out, CM_EINVAL, "scan_cl_fwd(xdbl): dir %d has a NULL tensor", i);

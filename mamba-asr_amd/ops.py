@@ -343,8 +343,14 @@ def _scan_cl_dir_rows(x, dd, u0, z, keep):
     return out
 
 
-def scan_cl_fwd(directions, z=None, delta_softplus=True):
+# time chunks of cm_scan_cl_fwd's xdbl mode: "auto" (cm_scan_cl_fwd_auto_chunks: cut sequences when the batch is too small
+# to fill the chip), or a fixed count (1 = never)
+SCAN_CHUNKS = os.environ.get("CM_SCAN_CHUNKS", "auto")
+
+
+def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None):
     """Channels-last selective scan, 1 or 2 directions in one launch (cm_scan_cl_fwd).
+    ``time_chunks`` (xdbl mode): None = the CM_SCAN_CHUNKS policy, else the chunk count.
 
     ``directions``: list of dicts with u, delta (batch, seqlen, dim), A (dim, 16), B, C (16, batch, seqlen) fp32
     time-contiguous (see alloc_bc), D, delta_bias (dim) or None, out (batch, seqlen, dim) view or None, reverse.
@@ -402,6 +408,18 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True):
         x.reverse_time = int(bool(dd.get("reverse", False)))
         outs.append(out)
     a.stream = _stream()
+    if "xdbl" in directions[0]:
+        if time_chunks is None:
+            time_chunks = (N.lib().cm_scan_cl_fwd_auto_chunks(b, l, d, len(directions)) if SCAN_CHUNKS == "auto"
+                           else int(SCAN_CHUNKS))
+        a.time_chunks = int(time_chunks)
+        nbytes = N.lib().cm_scan_cl_fwd_workspace_bytes(ct.byref(a))
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=u0.device)
+            keep.append(ws)
+            a.workspace, a.workspace_bytes = _ptr(ws), nbytes
+    elif time_chunks not in (None, 0, 1):
+        raise RuntimeError("time_chunks needs the xdbl mode")
     _launch("cm_scan_cl_fwd", N.lib().cm_scan_cl_fwd, a, units=b * l * len(directions))
     return outs
 

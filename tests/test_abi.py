@@ -20,7 +20,7 @@ def native():
 
 def test_header_symbols_exported(native):
     hdr = open(os.path.join(ROOT, "include", "conmamba_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|int64_t|const char \*)\s*\*?\s*(cm_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char \*)\s*\*?\s*(cm_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert {"cm_selective_scan_fwd", "cm_selective_scan_bwd", "cm_causal_conv1d_fwd", "cm_causal_conv1d_bwd",
             "cm_abi_version", "cm_last_error", "cm_scan_num_chunks", "cm_scan_set_split", "cm_debug_set", "cm_debug_get", "cm_scan_cl_fwd", "cm_conv_cl_fwd", "cm_conv_xproj", "cm_fbank_wav", "cm_cnn_front", "cm_ln_pw_glu", "cm_dwconv1d_fwd", "cm_dwconv1d_bwd", "cm_dwconv_cl_fwd", "cm_dwconv_cl_bwd", "cm_dwconv_cl_workspace_floats", "cm_causal_conv1d_update", "cm_selective_state_update", "cm_add_layernorm", "cm_layernorm_fwd", "cm_layernorm_bwd", "cm_layernorm_bwd_workspace_floats",
             "cm_glu_dwconv_ln_gelu", "cm_cnn_block1", "cm_gemm_bf16", "cm_fbank_mel_db", "cm_fbank_finish",

@@ -299,6 +299,70 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     close(got.float(), ref.transpose(1, 2), *((2e-3, 1e-4) if dtype == torch.float32 else (1.6e-2, 2e-2)))   # growing states: looser rtol
 
 
+@pytest.mark.parametrize("shape,chunks", [((2, 1000, 128), 4), ((1, 333, 72), 3), ((3, 205, 64), 8), ((1, 4000, 64), 16),
+                                          ((2, 50, 64), 7), ((2, 517, 136), 2)])
+@pytest.mark.parametrize("dtype,rank", [(torch.float32, 16), (torch.bfloat16, 9), (torch.bfloat16, 32)])
+def test_scan_rows_time_chunks(ops, shape, chunks, dtype, rank):
+    """cm_scan_cl_fwd with time_chunks > 1 (summary pass + carry fold + output pass, csrc/scan_rows_fwd.hip) against the
+    unchunked launch and the fp64 oracle, both directions, ragged last chunk, chunk counts that exceed the blocks there
+    are; then with a caller h0 and the whole-sequence h_last / decay outputs."""
+    from mamba_asr_amd import _native
+    b, l, e = shape
+    P = 16 if rank <= 16 else 32
+    RW = P + 32
+    gen = torch.Generator().manual_seed(l + 3 * e + chunks)
+    z = torch.randn(b, l, e, generator=gen).to(dtype).to(DEV)
+    dirs, refs = [], []
+    for i, rev in enumerate((False, True)):
+        u = torch.randn(b, l, e, generator=gen).to(dtype)
+        A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
+        xd = torch.randn(b, l, RW, generator=gen) * 0.5
+        xd[:, :, rank:P] = 0.0
+        xq = xd.to(dtype)
+        Wdt = torch.randn(e, rank, generator=gen) * 0.3
+        D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
+        xf = xq.float()
+        delta = torch.einsum("er,blr->bel", Wdt.to(dtype).double(), xf[:, :, :rank].double())
+        f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
+        tr = lambda t: t.float().transpose(1, 2)
+        ref = O.selective_scan(f(tr(u)), f(delta), A, f(tr(xf[:, :, P:P + 16])), f(tr(xf[:, :, P + 16:])), D, f(tr(z.cpu())), bias, True,
+                               work_dtype=torch.float64)
+        refs.append(f(ref).transpose(1, 2))
+        dirs.append(dict(u=u.to(DEV), A=A.to(DEV), D=D.to(DEV), delta_bias=bias.to(DEV), dt_weight=ops.pad_dt_weight(Wdt.to(DEV)),
+                         xdbl=xq.to(DEV), reverse=rev))
+    whole = ops.scan_cl_fwd([dict(d) for d in dirs], z=z, time_chunks=1)
+    ops.LAUNCH_LOG = log = []
+    try:
+        cut = ops.scan_cl_fwd([dict(d) for d in dirs], z=z, time_chunks=chunks)
+    finally:
+        ops.LAUNCH_LOG = None
+    assert [n for n, *_ in log] == ["cm_scan_cl_fwd"]
+    otol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
+    ctol = (1e-5, 1e-5) if dtype == torch.float32 else (8e-3, 1e-3)       # bf16: one output rounding apart at most
+    for i in range(2):
+        close(cut[i].float(), whole[i].float(), *ctol)
+        close(cut[i].float(), refs[i], *otol)
+    # caller-side carry through a chunked launch == through the unchunked one
+    st = lambda: torch.empty(b, e, 16, device=DEV)
+    h0 = [torch.randn(b, e, 16, generator=gen).to(DEV) for _ in range(2)]
+    outs = {}
+    for c in (1, chunks):
+        hl, dc = [st(), st()], [st(), st()]
+        y = ops.scan_cl_fwd([dict(d, h0=h0[i], h_last=hl[i], decay=dc[i]) for i, d in enumerate(dirs)], z=z, time_chunks=c)
+        outs[c] = (y, hl, dc)
+    for i in range(2):
+        close(outs[chunks][0][i].float(), outs[1][0][i].float(), *ctol)
+        close(outs[chunks][1][i], outs[1][1][i], 2e-5, 1e-6)
+        close(outs[chunks][2][i], outs[1][2][i], 2e-5, 1e-30)
+    # the sizes-only policy: small batches are cut, large ones are not
+    lib = _native.lib()
+    assert lib.cm_scan_cl_fwd_auto_chunks(64, 1000, 512, 2) == 1
+    assert lib.cm_scan_cl_fwd_auto_chunks(16, 1000, 512, 2) == 1
+    assert lib.cm_scan_cl_fwd_auto_chunks(8, 1000, 512, 2) == 8
+    assert lib.cm_scan_cl_fwd_auto_chunks(4, 4000, 1024, 2) == 8
+    assert lib.cm_scan_cl_fwd_auto_chunks(1, 100, 64, 1) == 1
+
+
 @pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 512), (2, 5, 96), (1, 33, 1024), (16, 1000, 512), (40, 403, 288)])
 def test_conv_xproj(ops, shape):
     """cm_conv_xproj == cm_conv_cl_fwd (bit-exact u) and x_dbl rows == u @ Wx^T computed in fp32 from the bf16 u and
