@@ -346,6 +346,10 @@ typedef struct cm_glu_dwconv_args {
     void *out;                   /* (batch, seqlen, dim), contiguous                   */
     void *stream;
     const float *weight_t;       /* optional (ksize, dim) copy of the taps: per-channel reads become coalesced */
+    const void  *lin_w;          /* optional: the module's closing Linear(dim, dim) (reference Conmamba.py:156-158) applied to
+                                    the tile before it is stored: (dim, dim) bf16 in cm_ffn_pack_weights' image; bf16 rows of
+                                    dim 256 only.  out = GELU(LayerNorm(conv)) @ lin_w^T + lin_b                          */
+    const float *lin_b;          /* (dim) fp32, required with lin_w                                                       */
 } cm_glu_dwconv_args;
 
 int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args);

@@ -163,7 +163,7 @@ class GluDwconvArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("glu_done", i32),
         ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
-        ("out", vp), ("stream", vp), ("weight_t", fp),
+        ("out", vp), ("stream", vp), ("weight_t", fp), ("lin_w", vp), ("lin_b", fp),
     ]
 
 

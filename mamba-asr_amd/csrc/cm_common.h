@@ -72,6 +72,11 @@ template <> struct cm_elem<cm_f16> {
 
 __device__ __forceinline__ float cm_bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float cm_bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t cm_pack_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{lo, hi}, v2b));
+}
 
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp)
 __device__ __forceinline__ float cm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

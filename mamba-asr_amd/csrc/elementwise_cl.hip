@@ -5,6 +5,8 @@
 // All are HBM-bound: 16-byte vectors along the contiguous channel axis, every input read once.
 #include "cm_common.h"
 
+extern "C" int cm_debug_get();
+
 namespace {
 
 template <typename IO> struct vec8 {                  // 16-byte vector of IO elements <-> floats
@@ -320,6 +322,177 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const cm_glu_dwconv_arg
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same module for bf16 rows with dim % 64 == 0 (d_model 256 / 512: the fused encoder route), re-tiled:
+//   * 32 output steps per workgroup: 62 input rows staged per 32 outputs (the 16-step tile above stages 46 per 16);
+//   * thread = (channel PAIR, half of the tile's steps): one 4-byte LDS read feeds two channels and the 31 x 16 taps run
+//     as v_pk_fma_f32, accumulating by INPUT row (one staged value live at a time; 16 x 2 accumulators + 31 x 2 taps
+//     in registers -- the gather form above keeps a 46-row window per thread);
+//   * the fp32 conv tile overlays the staged bf16 rows (outputs wait in registers across a barrier), so a workgroup holds
+//     (32 x (dim + 16)) x 4 bytes of LDS: four workgroups per CU at dim 256;
+//   * LayerNorm + GELU on rows of 16 lanes (dim / 16 values per lane, DPP sums), 8-byte stores.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+//   * LIN (dim 256): the convolution module's closing Linear (reference Conmamba.py:156-158, dim -> dim) runs on the tile
+//     before it leaves the CU -- activations to LDS (bf16, 528-byte rows), v_mfma_f32_16x16x32_bf16 with the weight rows as
+//     the A operand straight from their packed image in L2 (cm_ffn_pack_weights; ring filled during the LayerNorm phase),
+//     wave = 64 output features x 32 tokens, bias added in fp32.  It replaces a library GEMM that re-read the rows.
+typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float dw_f32x4;
+
+template <int K, int TT, int DV, bool LIN = false>
+__global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_kernel(const cm_glu_dwconv_args p) {
+    constexpr int D = DV * 64, NIN = TT + K - 1, TH = TT / 2, CS = D + 16, NIT = (D / 2 + 127) / 128;
+    constexpr int XS = D + 8;                                     // LIN: activation row stride in bf16 elements
+    static_assert(!LIN || (D == 256 && TT == 32), "the Linear epilogue is built for dim 256, 32-step tiles");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    uint16_t *g = reinterpret_cast<uint16_t *>(sm);               // [NIN][D] staged (gated) rows, bf16
+    float *co = sm;                                               // [TT][CS] conv outputs, overlays g after phase 2
+    uint16_t *xt = reinterpret_cast<uint16_t *>(sm + TT * CS);    // LIN: [TT][XS] activations, behind co
+    const int T = p.seqlen, tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const bool pre = p.glu_done != 0;
+    const int IW = pre ? D : 2 * D;
+    const uint16_t *in = reinterpret_cast<const uint16_t *>(p.in) + (int64_t)b * T * IW;
+    // phase 1: rows t0 - K/2 .. t0 + TT - 1 + K/2 -> LDS, zero outside the sequence ('same' padding)
+    for (int idx = tid; idx < NIN * (D / 8); idx += 256) {
+        const int r = idx / (D / 8), c = (idx % (D / 8)) * 8;
+        const int t = t0 - K / 2 + r;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (t >= 0 && t < T) {
+            v = *reinterpret_cast<const uint4 *>(in + (int64_t)t * IW + c);
+            if (!pre) {                                           // GLU: a * sigmoid(gate), gate = the row's second half
+                const uint4 q = *reinterpret_cast<const uint4 *>(in + (int64_t)t * IW + D + c);
+                const uint32_t av[4] = {v.x, v.y, v.z, v.w}, gv[4] = {q.x, q.y, q.z, q.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = cm_pack_bf16(cm_bf16_lo(av[j]) * cm_sigmoid(cm_bf16_lo(gv[j])), cm_bf16_hi(av[j]) * cm_sigmoid(cm_bf16_hi(gv[j])));
+                v = uint4{o[0], o[1], o[2], o[3]};
+            }
+        }
+        *reinterpret_cast<uint4 *>(g + r * D + c) = v;
+    }
+    __syncthreads();
+    // phase 2: depthwise conv, two channels x TH steps per thread, accumulated by input row
+    const int rh = tid >> 7;                                      // wave-uniform
+    f32x2_t acc[NIT][TH];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int cp = (tid & 127) + 128 * it;
+        const int c = 2 * (cp < D / 2 ? cp : 0);
+        f32x2_t w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            w[k] = p.weight_t ? *reinterpret_cast<const f32x2_t *>(p.weight_t + k * D + c) : f32x2_t{p.weight[c * K + k], p.weight[(c + 1) * K + k]};
+        const f32x2_t bias = p.bias ? *reinterpret_cast<const f32x2_t *>(p.bias + c) : f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < TH; ++r) acc[it][r] = bias;
+        const uint16_t *col = g + (rh * TH) * D + c;
+#pragma unroll
+        for (int j = 0; j < TH + K - 1; ++j) {                    // input row rh*TH + j feeds outputs r = j - k, 0 <= k < K
+            const uint32_t u = *reinterpret_cast<const uint32_t *>(col + j * D);
+            const f32x2_t x2 = {cm_bf16_lo(u), cm_bf16_hi(u)};
+#pragma unroll
+            for (int r = (j - (K - 1) > 0 ? j - (K - 1) : 0); r <= (j < TH - 1 ? j : TH - 1); ++r)
+                acc[it][r] = __builtin_elementwise_fma(w[j - r], x2, acc[it][r]);
+        }
+    }
+    __syncthreads();                                              // every thread is done reading g
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int cp = (tid & 127) + 128 * it;
+        if (cp < D / 2) {
+#pragma unroll
+            for (int r = 0; r < TH; ++r) *reinterpret_cast<f32x2_t *>(co + (rh * TH + r) * CS + 2 * cp) = acc[it][r];
+        }
+    }
+    __syncthreads();
+    // phase 3: LayerNorm + GELU, a row of 16 lanes per output row
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+    uint16_t *out = reinterpret_cast<uint16_t *>(p.out) + (int64_t)b * T * D;
+    // LIN: weight fragments of the wave's 64 output features, k-steps 0..PF-1 in flight under the LayerNorm phase
+    constexpr int PF = 4;
+    dw_bf16x8 wq[LIN ? PF : 1][4];
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.lin_w), 0, LIN ? D * D * 2 : 0, 0x00020000);
+    auto wload = [&](int ks, dw_bf16x8(&dst)[4]) {                 // fragment (16-row band, k-tile) = 1 KB at (band * D/32 + ks) * 1024
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            dst[mb] = __builtin_bit_cast(dw_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, ((wave * 4 + mb) * (D / 32) + ks) * 1024, 0));
+    };
+    if constexpr (LIN) {
+#pragma unroll
+        for (int s2 = 0; s2 < PF; ++s2) wload(s2, wq[s2]);
+    }
+    for (int r = wave * 4 + lq; r < TT; r += 16) {
+        const int t = t0 + r;
+        float4 v[DV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            v[i] = *reinterpret_cast<const float4 *>(co + r * CS + 4 * (l15 + 16 * i));
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = cm_group_sum<16>(s) * (1.f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            sq = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, sq))));
+        }
+        const float rstd = rsqrtf(cm_group_sum<16>(sq) * (1.f / D) + p.eps);
+        if (LIN || t < T) {
+#pragma unroll
+            for (int i = 0; i < DV; ++i) {
+                const int c = 4 * (l15 + 16 * i);
+                const float4 gm = *reinterpret_cast<const float4 *>(p.ln_g + c);
+                const float4 bt = *reinterpret_cast<const float4 *>(p.ln_b + c);
+                const float y0 = fmaf(v[i].x * rstd, gm.x, bt.x), y1 = fmaf(v[i].y * rstd, gm.y, bt.y);
+                const float y2 = fmaf(v[i].z * rstd, gm.z, bt.z), y3 = fmaf(v[i].w * rstd, gm.w, bt.w);
+                const uint2 pk = make_uint2(cm_gelu_bf16_pack2(y0, y1), cm_gelu_bf16_pack2(y2, y3));
+                if constexpr (LIN) *reinterpret_cast<uint2 *>(xt + r * XS + c) = pk;     // rows past the sequence: finite, never stored
+                else *reinterpret_cast<uint2 *>(out + (int64_t)t * D + c) = pk;
+            }
+        }
+    }
+    if constexpr (LIN) {
+        // phase 4: out[t][f] = sum_c W[f][c] act[t][c] + bias[f].  Lane holds token nb*16 + l15, features wave*64 + mb*16 + lq*4 + j.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // LDS only: the weight ring stays in flight
+        dw_f32x4 acc[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint16_t *frag = xt + l15 * XS + lq * 8;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+            dw_bf16x8 tok[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) tok[nb] = *reinterpret_cast<const dw_bf16x8 *>(frag + nb * 16 * XS + ks * 32);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks % PF][mb], tok[nb], acc[mb][nb], 0, 0, 0);
+            if (ks + PF < D / 32) wload(ks + PF, wq[ks % PF]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int f0 = wave * 64 + lq * 4;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 bv = *reinterpret_cast<const float4 *>(p.lin_b + f0 + mb * 16);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int t = t0 + nb * 16 + l15;
+                if (t < T)
+                    *reinterpret_cast<uint2 *>(out + (int64_t)t * D + f0 + mb * 16) =
+                        make_uint2(cm_pack_bf16(acc[mb][nb][0] + bv.x, acc[mb][nb][1] + bv.y), cm_pack_bf16(acc[mb][nb][2] + bv.z, acc[mb][nb][3] + bv.w));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // CNN block 1: conv 3x3 stride 2 (1 input channel) + LayerNorm(F1*C) + LeakyReLU, one workgroup per padded
 // output time row.  The three input rows live in LDS; each thread produces F1*C/256 outputs, the row statistics
 // are a block reduction, and the row (plus its reflected frequency border) is written once.
@@ -519,6 +692,28 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
                "glu_dwconv: bad sizes or NULL tensor");
     CM_REQUIRE(a.ksize == 31, CM_EUNSUPPORTED, "glu_dwconv: kernel size %d unsupported (31 only)", a.ksize);
     CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
+    hipStream_t st0 = reinterpret_cast<hipStream_t>(a.stream);
+    if (a.io_dtype == CM_BF16 && (a.dim == 256 || a.dim == 512) && cm_debug_get() != 31 && cm_aligned(a.in, 16) && cm_aligned(a.out, 8) &&
+        (!a.weight_t || cm_aligned(a.weight_t, 8)) && (!a.bias || cm_aligned(a.bias, 8)) && cm_aligned(a.ln_g, 16) && cm_aligned(a.ln_b, 16)) {
+        constexpr int TT = 32;
+        const dim3 grid((a.seqlen + TT - 1) / TT, a.batch);
+        const bool lin = a.lin_w != nullptr;
+        CM_REQUIRE(!lin || (a.dim == 256 && a.lin_b && cm_aligned(a.lin_w, 16) && cm_aligned(a.lin_b, 16)), CM_EUNSUPPORTED,
+                   "glu_dwconv: the Linear epilogue needs dim 256, lin_b, 16-byte aligned tensors");
+        const size_t lds_co = (size_t)TT * (a.dim + 16) * 4 + (lin ? (size_t)TT * (a.dim + 8) * 2 : 0), lds_g = (size_t)(TT + 30) * a.dim * 2;
+        const size_t smem = lds_co > lds_g ? lds_co : lds_g;
+        auto run = [&](auto kern) -> int {
+            if (smem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) { cm_set_error("glu_dwconv: LDS attribute failed: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), smem, st0, a);
+            return cm_launch_status("cm_glu_dwconv_ln_gelu(rows)");
+        };
+        if (lin) return run(dwconv_rows_kernel<31, TT, 4, true>);
+        return a.dim == 256 ? run(dwconv_rows_kernel<31, TT, 4>) : run(dwconv_rows_kernel<31, TT, 8>);
+    }
+    CM_REQUIRE(!a.lin_w, CM_EUNSUPPORTED, "glu_dwconv: the Linear epilogue is built for bf16 rows of dim 256 (16-byte aligned) only");
     // time tile: LDS holds (tt + K - 1 + tt) rows of dim floats; keep it under 64 KB so 2 workgroups share a CU
     const size_t el = a.io_dtype == CM_F32 ? 4 : 2;
     auto lds_bytes = [&](int t) { return (size_t)t * (a.dim + 16) * 4 + (size_t)(t + 30) * a.dim * el; };

@@ -96,6 +96,9 @@ class _LayerCache:
         self.dw_wt = self.dw_w.reshape(self.dw_w.shape[0], -1).t().contiguous()              # (k, D) taps, coalesced reads
         self.cm_ln2 = (f(cm.after_conv[0].weight), f(cm.after_conv[0].bias), cm.after_conv[0].eps)
         self.lin_w, self.lin_b = c(cm.after_conv[2].weight), c(cm.after_conv[2].bias)
+        self.lin_packed = None                                    # the same Linear inside cm_glu_dwconv_ln_gelu (bf16, d_model 256)
+        if USE_DWCONV_LIN and dtype == torch.bfloat16 and self.lin_w.is_cuda and tuple(self.lin_w.shape) == (256, 256) and self.lin_bf is not None:
+            self.lin_packed = ops.PackedWeight(self.lin_w)
         self.kernel_size = cm.kernel_size
 
     @staticmethod
@@ -132,6 +135,10 @@ def _ffn(x, y_in, p, dtype):
     else:
         h = F.gelu(torch.addmm(p["b1"], y_in, p["w1"].t()))
     return torch.addmm(p["b2"], h, p["w2"].t())
+
+
+# the convolution module's closing Linear inside cm_glu_dwconv_ln_gelu; CM_DWCONV_LIN=0 = library GEMM after the kernel
+USE_DWCONV_LIN = os.environ.get("CM_DWCONV_LIN", "1") == "1"
 
 
 # cm_scan_cl_fwd's xdbl mode (row-group scan kernel, csrc/scan_rows_fwd.hip); CM_SCAN_ROWS=0 keeps the state-split kernel
@@ -217,12 +224,13 @@ def _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln=None):
         # x += mamba ; conv-module LN ; pointwise conv ; GLU -- one kernel, the 2D-wide tensor never exists
         gl = ops.ln_pw_glu(x, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
         g = ops.glu_dwconv_ln_gelu(gl.view(batch, seqlen, D), c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2],
-                                   weight_t=c.dw_wt, glu_done=True)
+                                   weight_t=c.dw_wt, glu_done=True, lin_w=c.lin_packed, lin_b=c.lin_bf)
     else:
         _, h = ops.add_layernorm(x, y, 1.0, x_out=x, norm2=c.cm_ln, out_dtype=dtype)          # x += mamba ; conv-module LN
         pw = torch.addmm(c.pw_b, h, c.pw_w.t()).view(batch, seqlen, 2 * D)
-        g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt)
-    y = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
+        g = ops.glu_dwconv_ln_gelu(pw, c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2], weight_t=c.dw_wt,
+                                   lin_w=c.lin_packed, lin_b=c.lin_bf)
+    y = g if c.lin_packed is not None else torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
     # x = norm2(x + conv + 0.5 ffn2(x + conv)); the encoder's final norm rides along on the last layer
     if final_ln is not None:
         _, out = ops.ffn_fused(x, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=y.view(-1, D),
@@ -377,8 +385,8 @@ def _encoder_forward_joined(encoder, src, dtype, ns):
                     y = ycat[b0:b1].view(-1, 2 * E) @ c.out_cat.t()
                     gl = ops.ln_pw_glu(xp, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
                     g = ops.glu_dwconv_ln_gelu(gl.view(b1 - b0, seqlen, D), c.dw_w, c.dw_b, c.cm_ln2[0], c.cm_ln2[1], c.cm_ln2[2],
-                                               weight_t=c.dw_wt, glu_done=True)
-                    yl = torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
+                                               weight_t=c.dw_wt, glu_done=True, lin_w=c.lin_packed, lin_b=c.lin_bf)
+                    yl = g.view(-1, D) if c.lin_packed is not None else torch.addmm(c.lin_b, g.view(-1, D), c.lin_w.t())
                     if li == n - 1:
                         _, outs[pi] = ops.ffn_fused(xp, f2["ln"], f2["w1p"], f2["b1f"], f2["w2p"], f2["b2f"], alpha=0.5, addend=yl,
                                                     norm1=c.norm2, norm2=fin, h_dtype=torch.float32)

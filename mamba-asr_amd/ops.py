@@ -748,7 +748,7 @@ def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
     return out
 
 
-def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None, glu_done=False):
+def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None, glu_done=False, lin_w=None, lin_b=None):
     """(batch, seqlen, 2*dim) -> (batch, seqlen, dim): GLU, depthwise conv (k=31, same padding), LayerNorm, GELU
     (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k); weight_t: optional precomputed fp32 (k, dim) copy of the
     taps (made here per call otherwise) so that the kernel's per-channel tap reads are coalesced."""
@@ -767,6 +767,11 @@ def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t
     if wt.dtype != torch.float32 or wt.shape != (w.shape[1], d) or not wt.is_contiguous():
         raise RuntimeError("glu_dwconv_ln_gelu: weight_t must be a contiguous fp32 (k, dim) tensor")
     a.weight_t = _ptr(wt)
+    if lin_w is not None:                                 # closing Linear(dim, dim) of the module, applied in the same kernel
+        if not isinstance(lin_w, PackedWeight) or lin_w.shape != (d, d) or lin_b is None:
+            raise RuntimeError("glu_dwconv_ln_gelu: lin_w must be a PackedWeight of shape (dim, dim), with lin_b")
+        lb = _f32c(lin_b)
+        a.lin_w, a.lin_b = _ptr(lin_w.data), _ptr(lb)
     a.stream = _stream()
     _launch("cm_glu_dwconv_ln_gelu", N.lib().cm_glu_dwconv_ln_gelu, a, units=b * l)
     return out

@@ -276,6 +276,51 @@ def test_ln_pw_glu_kernel_and_pregated_dwconv(batch, seqlen):
     torch.testing.assert_close(a.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("batch,seqlen", [(2, 100), (3, 37), (1, 1000), (2, 31), (1, 1)])
+def test_dwconv_rows_kernel(D, batch, seqlen):
+    """cm_glu_dwconv_ln_gelu's 32-step row kernel (bf16, dim 256 / 512; csrc/elementwise_cl.hip dwconv_rows_kernel): GLU ->
+    depthwise conv 31 ('same') -> LayerNorm -> GELU (reference Conmamba.py:120-160) vs torch fp32 on the same bf16 inputs,
+    with and without the transposed tap copy, pre-gated and not, and against the 16-step kernel it replaces."""
+    from mamba_asr_amd import ops, _native
+    F = torch.nn.functional
+    g = torch.Generator(device="cpu").manual_seed(seqlen + D)
+    inp = torch.randn(batch, seqlen, 2 * D, generator=g).bfloat16()
+    w, bs = torch.randn(D, 31, generator=g) / 6, torch.randn(D, generator=g) * 0.1
+    lg, lb = 1.0 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    gated = (inp[..., :D].float() * torch.sigmoid(inp[..., D:].float())).bfloat16()
+    ref = F.conv1d(gated.float().transpose(1, 2), w[:, None], bs, padding=15, groups=D).transpose(1, 2)
+    ref = F.gelu(F.layer_norm(ref, (D,), lg, lb, 1e-5))
+    dev = lambda t: t.to(DEV)
+    wt = w.t().contiguous()
+    a = ops.glu_dwconv_ln_gelu(dev(inp), dev(w), dev(bs), dev(lg), dev(lb), 1e-5)
+    b_ = ops.glu_dwconv_ln_gelu(dev(inp), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt))
+    c = ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt), glu_done=True)
+    assert torch.equal(a, b_)
+    torch.testing.assert_close(a.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
+    torch.testing.assert_close(c.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
+    assert (c.float().cpu() - ref).abs().mean() < 1.5e-3
+    _native.lib().cm_debug_set(31)                                # the 16-step kernel
+    try:
+        old = ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt), glu_done=True)
+    finally:
+        _native.lib().cm_debug_set(0)
+    torch.testing.assert_close(c.float(), old.float(), rtol=8e-3, atol=2e-3)       # fp32 sums in a different order, one bf16 rounding
+    # the module's closing Linear in the same kernel (dim 256) == the kernel's bf16 activations through a fp32 matmul
+    lw, lbias = (torch.randn(D, D, generator=g) / 16).bfloat16(), torch.randn(D, generator=g) * 0.1
+    if D == 256:
+        y = ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt), glu_done=True,
+                                   lin_w=ops.PackedWeight(dev(lw)), lin_b=dev(lbias))
+        want = c.float().cpu() @ lw.float().t() + lbias
+        torch.testing.assert_close(y.float().cpu(), want, rtol=8e-3, atol=4e-3)
+        y2 = ops.glu_dwconv_ln_gelu(dev(inp), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, lin_w=ops.PackedWeight(dev(lw)), lin_b=dev(lbias))
+        assert torch.equal(y, y2)
+    else:
+        with pytest.raises(RuntimeError, match="dim 256"):
+            ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, glu_done=True,
+                                   lin_w=ops.PackedWeight(dev(lw)), lin_b=dev(lbias))
+
+
 @pytest.mark.parametrize("batch,frames", [(2, 401), (3, 130), (1, 4001), (2, 37), (70, 64)])
 def test_cnn_front_kernel(batch, frames):
     """cm_cnn_front (both CNN blocks, intermediate kept in LDS) against (a) a torch fp32 restatement of
