@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 4)")
+    ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 2)")
     ap.add_argument("--stream-mode", choices=["join", "free"], default=None,
                     help="join (default): the scan runs once per layer on the whole batch; free: fully independent parts")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
@@ -250,7 +250,22 @@ def run_train(a, cfg, dev, rank, world, use_dist):
                 "exposed_comm_ms_per_optimizer_step": round(1e3 * sum(exposed) / len(exposed), 3) if exposed else None,
                 "optimizer_steps": brain.optimizer_step, "loss_first_last": [round(losses[0], 3), round(losses[-1], 3)],
                 "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "roofline": roof, "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
+        emit(line)
+
+
+_result_fd = None
+
+
+def emit(line: dict) -> None:
+    """The result line goes to the process's original stdout; everything else this process (or a library it loads: RCCL's
+    version banner, libdrm's complaints) writes to file descriptor 1 has been pointed at stderr, so stdout carries
+    exactly one line."""
+    data = (json.dumps(line) + "\n").encode()
+    if _result_fd is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_result_fd, data)
 
 
 def main():
@@ -258,6 +273,10 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # started by torch.distributed.run
     if not launched and a.gpus > 1:
         sys.exit(launch_ranks(a))
+    global _result_fd
+    sys.stdout.flush()
+    _result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -374,7 +393,7 @@ def main():
             "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
             "roofline": roof, "cpu_baseline": base,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         dist.destroy_process_group()
 

@@ -341,14 +341,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float dw_f32x4;
 
 template <int K, int TT, int DV, bool LIN = false>
-__global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_kernel(const cm_glu_dwconv_args p) {
+__global__ __launch_bounds__(256, DV == 4 ? 4 : 2) void dwconv_rows_kernel(const cm_glu_dwconv_args p) {
     constexpr int D = DV * 64, NIN = TT + K - 1, TH = TT / 2, CS = D + 16, NIT = (D / 2 + 127) / 128;
     constexpr int XS = D + 8;                                     // LIN: activation row stride in bf16 elements
     static_assert(!LIN || (D == 256 && TT == 32), "the Linear epilogue is built for dim 256, 32-step tiles");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     uint16_t *g = reinterpret_cast<uint16_t *>(sm);               // [NIN][D] staged (gated) rows, bf16
     float *co = sm;                                               // [TT][CS] conv outputs, overlays g after phase 2
-    uint16_t *xt = reinterpret_cast<uint16_t *>(sm + TT * CS);    // LIN: [TT][XS] activations, behind co
+    uint16_t *xt = reinterpret_cast<uint16_t *>(sm);              // LIN: [TT][XS] activations, overlays co after phase 3
     const int T = p.seqlen, tid = threadIdx.x;
     const int b = blockIdx.y, t0 = blockIdx.x * TT;
     const bool pre = p.glu_done != 0;
@@ -412,8 +412,9 @@ __global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
     uint16_t *out = reinterpret_cast<uint16_t *>(p.out) + (int64_t)b * T * D;
     // LIN: weight fragments of the wave's 64 output features, k-steps 0..PF-1 in flight under the LayerNorm phase
-    constexpr int PF = 4;
+    constexpr int PF = 2;                                         // 2-deep: 128 VGPRs, four workgroups per CU
     dw_bf16x8 wq[LIN ? PF : 1][4];
+    uint2 held[LIN ? TT / 16 : 1][DV];                            // LIN: a lane's activations wait here until every wave has read co
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.lin_w), 0, LIN ? D * D * 2 : 0, 0x00020000);
     auto wload = [&](int ks, dw_bf16x8(&dst)[4]) {                 // fragment (16-row band, k-tile) = 1 KB at (band * D/32 + ks) * 1024
 #pragma unroll
@@ -424,7 +425,9 @@ __global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_
 #pragma unroll
         for (int s2 = 0; s2 < PF; ++s2) wload(s2, wq[s2]);
     }
-    for (int r = wave * 4 + lq; r < TT; r += 16) {
+#pragma unroll
+    for (int it = 0; it < TT / 16; ++it) {
+        const int r = wave * 4 + lq + 16 * it;
         const int t = t0 + r;
         float4 v[DV];
         float s = 0.f;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_
                 const float y0 = fmaf(v[i].x * rstd, gm.x, bt.x), y1 = fmaf(v[i].y * rstd, gm.y, bt.y);
                 const float y2 = fmaf(v[i].z * rstd, gm.z, bt.z), y3 = fmaf(v[i].w * rstd, gm.w, bt.w);
                 const uint2 pk = make_uint2(cm_gelu_bf16_pack2(y0, y1), cm_gelu_bf16_pack2(y2, y3));
-                if constexpr (LIN) *reinterpret_cast<uint2 *>(xt + r * XS + c) = pk;     // rows past the sequence: finite, never stored
+                if constexpr (LIN) held[it][i] = pk;             // rows past the sequence: finite, never stored
                 else *reinterpret_cast<uint2 *>(out + (int64_t)t * D + c) = pk;
             }
         }
@@ -458,6 +461,12 @@ __global__ __launch_bounds__(256, LIN ? 3 : (DV == 4 ? 4 : 2)) void dwconv_rows_
     if constexpr (LIN) {
         // phase 4: out[t][f] = sum_c W[f][c] act[t][c] + bias[f].  Lane holds token nb*16 + l15, features wave*64 + mb*16 + lq*4 + j.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // LDS only: the weight ring stays in flight
+#pragma unroll
+        for (int it = 0; it < TT / 16; ++it)
+#pragma unroll
+            for (int i = 0; i < DV; ++i)
+                *reinterpret_cast<uint2 *>(xt + (wave * 4 + lq + 16 * it) * XS + 4 * (l15 + 16 * i)) = held[it][i];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         dw_f32x4 acc[4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -700,7 +709,7 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
         const bool lin = a.lin_w != nullptr;
         CM_REQUIRE(!lin || (a.dim == 256 && a.lin_b && cm_aligned(a.lin_w, 16) && cm_aligned(a.lin_b, 16)), CM_EUNSUPPORTED,
                    "glu_dwconv: the Linear epilogue needs dim 256, lin_b, 16-byte aligned tensors");
-        const size_t lds_co = (size_t)TT * (a.dim + 16) * 4 + (lin ? (size_t)TT * (a.dim + 8) * 2 : 0), lds_g = (size_t)(TT + 30) * a.dim * 2;
+        const size_t lds_co = (size_t)TT * (a.dim + 16) * 4, lds_g = (size_t)(TT + 30) * a.dim * 2;
         const size_t smem = lds_co > lds_g ? lds_co : lds_g;
         auto run = [&](auto kern) -> int {
             if (smem > 48 * 1024) {

@@ -12,6 +12,8 @@
 // registers; only x (once in, once out) and the D-wide bf16 g touch HBM.
 #include "cm_common.h"
 
+extern "C" int cm_debug_get();
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -22,14 +24,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int D = 256;        // d_model
 constexpr int TOK = 64;       // tokens per workgroup
 constexpr int XS = 264;       // LDS row stride in bf16 elements (528 bytes)
-constexpr int PF = 4;         // weight-fragment ring depth
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-__global__ __launch_bounds__(256, 3) void ln_pw_glu_kernel(const cm_ln_pw_glu_args p) {
+// OCC: workgroups per CU the register budget is cut for; PF: weight-fragment ring depth (k-steps in flight)
+template <int OCC, int PF>
+__global__ __launch_bounds__(256, OCC) void ln_pw_glu_kernel(const cm_ln_pw_glu_args p) {
     __shared__ __attribute__((aligned(16))) uint16_t xn[TOK * XS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,6 +171,12 @@ extern "C" int cm_ln_pw_glu(const cm_ln_pw_glu_args *args) {
     CM_REQUIRE(cm_aligned(a.x, 16) && cm_aligned(a.ln_g, 16) && cm_aligned(a.ln_b, 16) && cm_aligned(a.w, 16) && cm_aligned(a.bias, 16) &&
                    cm_aligned(a.out, 8) && (!a.y || cm_aligned(a.y, 8)) && (!a.x_out || cm_aligned(a.x_out, 16)),
                CM_EALIGN, "ln_pw_glu: tensors must be 16-byte aligned (y / out 8)");
-    hipLaunchKernelGGL(ln_pw_glu_kernel, dim3((a.rows + TOK - 1) / TOK), dim3(256), 0, reinterpret_cast<hipStream_t>(a.stream), a);
+    const dim3 grid((a.rows + TOK - 1) / TOK);
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    // four workgroups per CU (128 VGPRs with a 2-deep weight ring): 64 k rows = 1000 workgroups run in ONE round of 1024 slots;
+    // at three per CU (4-deep ring, 154 VGPRs) the last 232 ran alone: 69 -> 58 us in the encoder (profiles/r02).
+    // cm_debug_set(41) keeps the old shape for A/B runs.
+    if (cm_debug_get() == 41) hipLaunchKernelGGL((ln_pw_glu_kernel<3, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((ln_pw_glu_kernel<4, 2>), grid, dim3(256), 0, st, a);
     return cm_launch_status("cm_ln_pw_glu");
 }

@@ -319,7 +319,7 @@ def layer_forward_native(layer, x, h, batch, seqlen, next_ln):
 #           memory-bound kernels of the other parts -- but every kernel's duration then includes the time it shares the
 #           chip (the scan's measured roofline fraction halves), so it is not the default.
 # CM_STREAMS=1 disables.
-N_STREAMS = int(os.environ.get("CM_STREAMS", "4"))
+N_STREAMS = int(os.environ.get("CM_STREAMS", "2"))
 STREAM_MODE = os.environ.get("CM_STREAM_MODE", "join")
 _side_streams = {}
 
