@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 struct front_lds {
     uint16_t rows[NR][F1P][CS];           // block-1 output tile (bf16), slot = padded row index mod NR
     float ot[NB * 16][OTS];               // block-2 conv outputs of the tile
-    float fin[8][3][FW];                  // per-wave reflect-padded feature rows
+    float fin[8][3][2][FW];               // per-wave reflect-padded feature rows, twice: copy 1 is copy 0 shifted by two bins,
+                                          // so that a lane of either frequency parity reads its 3-tap window 16-byte aligned
     float ln1[2][F1 * C1];                // block-1 LayerNorm weight / bias
     bf16x8 wfrag[2][18][64];              // block-2 weights as MFMA A-operand fragment images (36 KB; in registers they
 };                                        // cost 144 VGPRs and pushed the block-1 row computation into scratch)
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
     for (int cb = 0; cb < 2; ++cb)
         bias2[cb] = p.b2 ? *reinterpret_cast<const float4 *>(p.b2 + cb * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int cp = lane & 31, fh = lane >> 5;                     // block 1: channel pair, frequency parity
-    float w1a[9], w1b[9];
+    f32x2 w1[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { w1a[k] = p.w1[(2 * cp) * 9 + k]; w1b[k] = p.w1[(2 * cp + 1) * 9 + k]; }
+    for (int k = 0; k < 9; ++k) w1[k] = f32x2{p.w1[(2 * cp) * 9 + k], p.w1[(2 * cp + 1) * 9 + k]};
     const float b1a = p.b1 ? p.b1[2 * cp] : 0.f, b1b = p.b1 ? p.b1[2 * cp + 1] : 0.f;
     for (int i = tid; i < F1 * C1; i += 512) { L.ln1[0][i] = p.ln1_g[i]; L.ln1[1][i] = p.ln1_b[i]; }
 
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = lane + 64 * k;
-            if (idx < 3 * 82) L.fin[wave][idx / 82][idx % 82] = r[k];
+            if (idx < 3 * 82) {
+                const int rr = idx / 82, fc = idx % 82;
+                L.fin[wave][rr][0][fc] = r[k];
+                if (fc >= 2) L.fin[wave][rr][1][fc - 2] = r[k];
+            }
         }
     };
     // one block-1 row (from this wave's staged feature rows) -> tile slot
@@ -111,19 +116,19 @@ __global__ __launch_bounds__(512) void cnn_front_kernel(const cm_cnn_front_args 
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < F1 / 2; ++i) {
-            const int f1 = 2 * i + fh;
-            float a0 = b1a, a1 = b1b;
+            // output bin f1 = 2 i + fh reads bins 2 f1 .. 2 f1 + 2 of the padded rows = floats 4 i .. 4 i + 2 of copy fh: one
+            // 16-byte read per input row (the lanes of one parity share the address: broadcast), both channels of the
+            // lane's pair per v_pk_fma_f32
+            f32x2 a2 = {b1a, b1b};
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
+            for (int dt = 0; dt < 3; ++dt) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&L.fin[wave][dt][fh][4 * i]);
 #pragma unroll
-                for (int df = 0; df < 3; ++df) {
-                    const float x = L.fin[wave][dt][2 * f1 + df];
-                    a0 = fmaf(w1a[dt * 3 + df], x, a0);
-                    a1 = fmaf(w1b[dt * 3 + df], x, a1);
-                }
-            v[2 * i] = a0; v[2 * i + 1] = a1;
-            s += a0 + a1;
-            if (i & 1) __builtin_amdgcn_sched_barrier(0);        // keeps the compiler from hoisting all 180 LDS reads (spills)
+                for (int df = 0; df < 3; ++df) a2 = __builtin_elementwise_fma(w1[dt * 3 + df], f32x2{xv[df], xv[df]}, a2);
+            }
+            v[2 * i] = a2.x; v[2 * i + 1] = a2.y;
+            s += a2.x + a2.y;
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);        // keeps the compiler from hoisting all 60 LDS reads (spills)
         }
         const float mean = wave_sum64(s) * (1.f / (F1 * C1));
         float sq = 0.f;

@@ -37,7 +37,13 @@ __device__ __forceinline__ void bfly4(cf &a0, cf &a1, cf &a2, cf &a3) {
 
 // LDS position of FFT element p: 4 pad elements per 16 spread the strided butterflies of stages 1 and 2 over the banks
 __device__ __forceinline__ int zp(int p) { return p + 4 * (p >> 4); }
-constexpr int ZN = NH + NH / 4;       // padded work-buffer length
+// ... and from the output of stage 2 on, one pad element per 4: stage 3 and the split step have every lane walk FOUR
+// CONSECUTIVE elements (lane stride 4 elements = 32 bytes: 4-way conflicts on the 8-byte accesses under zp -- rocprofv3
+// counted 70 % of this kernel's LDS cycles as bank conflicts and the LDS array busy 85 % of its duration); with a lane
+// stride of 5 elements the 32 lanes of a ds_read_b64 group hit 32 different 8-byte slots.  Stage 2 reads under zp and
+// writes under zq: a wave's LDS instructions execute in order and its four reads cover the whole buffer before the first write.
+__device__ __forceinline__ int zq(int p) { return p + (p >> 2); }
+constexpr int ZN = NH + NH / 4;       // padded work-buffer length (both paddings)
 
 __device__ __forceinline__ int rev4_8bit(int k) {                     // reverse the four base-4 digits of k < 256
     return ((k & 3) << 6) | ((k & 12) << 2) | ((k >> 2) & 12) | (k >> 6);
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;
-        ppos[i] = zp(rev4_8bit((NH - k) & (NH - 1)));
+        ppos[i] = zq(rev4_8bit((NH - k) & (NH - 1)));
         wk[i] = tw[k];
     }
     const int r3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);  // Z[lane + 64 i] sits at position 4 r3 + i
@@ -89,14 +95,15 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
     cf *z = zb + wave * ZN;
 
     // positions (padded) of this lane's butterfly operands in stages 0..3 and of its split-step reads
-    int p0[4], p1[4], p2[4], p3[4], ps[4];
+    int p0[4], p1[4], p2[4], p2w[4], p3[4], ps[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         p0[q] = zp(lane + 64 * q);
         p1[q] = zp(64 * (lane >> 4) + (lane & 15) + 16 * q);
         p2[q] = zp(16 * (lane >> 2) + (lane & 3) + 4 * q);
-        p3[q] = zp(4 * lane + q);
-        ps[q] = zp(4 * r3 + q);
+        p2w[q] = zq(16 * (lane >> 2) + (lane & 3) + 4 * q);
+        p3[q] = zq(4 * lane + q);
+        ps[q] = zq(4 * r3 + q);
     }
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     // frame t covers samples t*hop - 256 .. +255 (center=True); outside [0, samples) the buffer load returns 0.
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
             // stage 2 (L = 16): block = lane / 4, j = lane % 4
             a[0] = z[p2[0]]; a[1] = z[p2[1]]; a[2] = z[p2[2]]; a[3] = z[p2[3]];
             bfly4(a[0], a[1], a[2], a[3]);
-            z[p2[0]] = a[0]; z[p2[1]] = cmul(a[1], w2[0]); z[p2[2]] = cmul(a[2], w2[1]); z[p2[3]] = cmul(a[3], w2[2]);
+            z[p2w[0]] = a[0]; z[p2w[1]] = cmul(a[1], w2[0]); z[p2w[2]] = cmul(a[2], w2[1]); z[p2w[3]] = cmul(a[3], w2[2]);
             // stage 3 (L = 4): positions 4 lane .. 4 lane + 3, no twiddles
             a[0] = z[p3[0]]; a[1] = z[p3[1]]; a[2] = z[p3[2]]; a[3] = z[p3[3]];
             bfly4(a[0], a[1], a[2], a[3]);
