@@ -22,8 +22,13 @@ constexpr int FT = 16;            // frames per workgroup (4 per wave)
 constexpr int PWS = FT + 1;       // power-tile row stride (odd: conflict-free mel loop)
 constexpr int NF = 512;           // n_fft
 constexpr int NH = NF / 2;        // complex FFT length
+constexpr int BWCAP = 1024;       // band weights staged in LDS (triangular filters: <= 2 per bin = 514 for 257 bins); a larger
+                                  // table is read from global memory instead.  4 KB instead of the table's 16 KB bound: a
+                                  // workgroup holds 32.5 KB of LDS and four of them (16 waves) share a CU
 
-struct cf { float re, im; };
+// 8-byte aligned: LDS accesses are ds_read_b64 / ds_write_b64 (a 4-byte aligned pair compiles to ds_read2_b32, whose two
+// dword accesses are banked separately modulo 32 dwords: every element access of the padded layouts below was 2-way)
+struct __attribute__((aligned(8))) cf { float re, im; };
 __device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cf cmul(cf a, cf b) { return {fmaf(a.re, b.re, -a.im * b.im), fmaf(a.re, b.im, a.im * b.re)}; }
@@ -55,15 +60,15 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
     const int F = NH + 1, T = p.frames, M = p.n_mels;
     float *pw = sm;                                               // [F][PWS] power tile
     int *band = reinterpret_cast<int *>(pw + F * PWS);            // [3 M + 1]
-    float *bw = reinterpret_cast<float *>(band + 3 * M + 1);      // [4096] packed band weights
-    cf *zb = reinterpret_cast<cf *>(bw + 4096);                   // [4 waves][ZN] FFT work buffers (padded)
+    float *bw = reinterpret_cast<float *>(band + 3 * M + 1);      // [BWCAP] packed band weights
+    cf *zb = reinterpret_cast<cf *>(bw + BWCAP + ((3 * M + 1 + F * PWS) & 1));  // [4 waves][ZN] FFT work buffers (padded), 8-byte aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int m = tid; m < M; m += 256) { band[m] = p.band_lo[m]; band[M + m] = p.band_hi[m]; }
     for (int m = tid; m <= M; m += 256) band[2 * M + m] = p.band_off[m];
-    {
-        const int total = p.band_off[M];
-        for (int i = tid; i < total; i += 256) bw[i] = p.band_w[i];
-    }
+    const int bw_total = p.band_off[M];
+    const bool bw_lds = bw_total <= BWCAP;
+    if (bw_lds)
+        for (int i = tid; i < bw_total; i += 256) bw[i] = p.band_w[i];
 
     // ---- per-lane constants
     const cf *tw = reinterpret_cast<const cf *>(p.twiddle);       // tw[k] = exp(-2 pi i k / 512)
@@ -160,18 +165,34 @@ __global__ __launch_bounds__(256) void fbank_wav_kernel(const cm_fbank_args p) {
     }
     __syncthreads();
 
-    // ---- mel projection + dB (as cm_fbank_mel_db)
+    // ---- mel projection + dB.  thread = (mel band, frame) with the FRAME fastest: a wave's 64 lanes are 4 bands x 16
+    // frames, so a power-tile read is 16 consecutive floats per band (at most 2-way bank conflicts between the two bands of a
+    // 32-lane group; with the band fastest, bands whose first bins are 8 apart met on 4 banks: 8-way), the weight read is
+    // a broadcast per band, and the loop length is that of 4 neighbouring bands, not of the 64 widest.
+    // dB values pass through LDS so that the global stores are whole 320-byte frame rows.
     float local_max = -INFINITY;
+    static_assert(FT == 16, "the mel stage maps 16 frames to 16 lanes");
+    float *dbt = reinterpret_cast<float *>(zb);                  // [FT][M] dB tile; the FFT buffers are dead (barrier above)
     for (int o = tid; o < FT * M; o += 256) {
-        const int j = o / M, m = o % M;
-        if (t0 + j >= T) continue;
+        const int m = o >> 4, j = o & 15;
         float acc = 0.f;
         const int lo = band[m], hi = band[M + m];
-        const float *wm = bw + band[2 * M + m] - lo;
-        for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], wm[f], acc);
+        if (bw_lds) {                                             // (two loops: one address space per pointer)
+            const float *wm = bw + band[2 * M + m] - lo;
+            for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], wm[f], acc);
+        } else {
+            const float *wm = p.band_w + band[2 * M + m] - lo;
+            for (int f = lo; f < hi; ++f) acc = fmaf(pw[f * PWS + j], wm[f], acc);
+        }
         const float db = 10.f * log10f(fmaxf(acc, p.amin));
-        p.db[((int64_t)b * T + t0 + j) * M + m] = db;
-        local_max = fmaxf(local_max, db);
+        dbt[j * M + m] = db;
+        if (t0 + j < T) local_max = fmaxf(local_max, db);
+    }
+    __syncthreads();
+    {
+        const int nrow = min(FT, T - t0);                         // rows t0 .. t0 + nrow - 1 are contiguous in db: one linear copy
+        float *dst = p.db + ((int64_t)b * T + t0) * M;
+        for (int i = tid; i < nrow * M; i += 256) dst[i] = dbt[i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off, 64));
@@ -194,7 +215,7 @@ extern "C" int cm_fbank_wav(const cm_fbank_args *args) {
                "fbank_wav: hop and the batch stride must be even, wav / window / twiddle 8-byte aligned");
     CM_REQUIRE(a.frames == 1 + a.samples / a.hop, CM_EINVAL, "fbank_wav: frames must be 1 + samples / hop (center=True)");
     CM_REQUIRE(a.batch <= 65535 && a.n_mels <= 128, CM_EUNSUPPORTED, "fbank_wav: batch / n_mels too large");
-    const size_t smem = (size_t)(NH + 1) * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (size_t)4096 * 4 + (size_t)4 * ZN * 8;
+    const size_t smem = (size_t)(NH + 1) * PWS * 4 + (size_t)(3 * a.n_mels + 1) * 4 + (size_t)BWCAP * 4 + (size_t)4 * ZN * 8 + 4;
     dim3 grid((a.frames + FT - 1) / FT, a.batch);
     hipLaunchKernelGGL(fbank_wav_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_fbank_wav");
