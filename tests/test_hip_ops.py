@@ -358,7 +358,7 @@ def test_scan_rows_time_chunks(ops, shape, chunks, dtype, rank):
     lib = _native.lib()
     assert lib.cm_scan_cl_fwd_auto_chunks(64, 1000, 512, 2) == 1
     assert lib.cm_scan_cl_fwd_auto_chunks(16, 1000, 512, 2) == 1
-    assert lib.cm_scan_cl_fwd_auto_chunks(8, 1000, 512, 2) == 8
+    assert lib.cm_scan_cl_fwd_auto_chunks(8, 1000, 512, 2) == 7      # 1024 / 128 workgroups = 8, capped at 1000 // 128 steps
     assert lib.cm_scan_cl_fwd_auto_chunks(4, 4000, 1024, 2) == 8
     assert lib.cm_scan_cl_fwd_auto_chunks(1, 100, 64, 1) == 1
 
