@@ -39,6 +39,26 @@ def test_abi_version_and_chunks(native):
     assert lib.cm_scan_num_chunks(65) == 2
 
 
+def test_scan_chunk_policy_and_workspace_are_host_functions(native):
+    """cm_scan_cl_fwd_auto_chunks / cm_scan_cl_fwd_workspace_bytes depend on sizes only (no GPU): large launches are not
+    cut, launches of fewer than 256 workgroups are cut to ~1024 with chunks of at least 128 steps, and the workspace is
+    three (ndir, batch, chunks, dim, 16) fp32 slabs for the chunk count the launch will really use."""
+    lib = native.lib()
+    auto = lib.cm_scan_cl_fwd_auto_chunks
+    assert auto(64, 1000, 512, 2) == 1 and auto(16, 1000, 512, 2) == 1          # >= 256 workgroups
+    assert auto(8, 1000, 512, 2) == 7                                           # 1024 // 128 = 8, capped at 1000 // 128
+    assert auto(4, 4000, 1024, 2) == 8 and auto(1, 4000, 512, 2) == 31
+    assert auto(1, 100, 64, 1) == 1 and auto(0, 100, 64, 1) == 1
+    a = native.ScanClArgs()
+    a.batch, a.seqlen, a.dim, a.ndir = 4, 4000, 1024, 2
+    assert lib.cm_scan_cl_fwd_workspace_bytes(C.byref(a)) == 0                  # time_chunks 0 / 1: none
+    a.time_chunks = 8                                                           # 4000 / 8 = 500 -> 512-step chunks -> 8 chunks
+    assert lib.cm_scan_cl_fwd_workspace_bytes(C.byref(a)) == 3 * 2 * 4 * 8 * 1024 * 16 * 4
+    a.seqlen, a.time_chunks = 50, 7                                             # 16-step chunks -> 4 chunks, not 7
+    assert lib.cm_scan_cl_fwd_workspace_bytes(C.byref(a)) == 3 * 2 * 4 * 4 * 1024 * 16 * 4
+    assert lib.cm_scan_cl_fwd_workspace_bytes(None) == 0
+
+
 def test_bad_arguments_are_rejected_not_fatal(native):
     lib = native.lib()
     a = native.ScanFwdArgs()          # all zero: sizes invalid
