@@ -73,7 +73,9 @@ class Brain:
                 for g in opt.param_groups:
                     if g.get("fused") is None and not g.get("capturable", False) and not g.get("differentiable", False):
                         g["fused"], g["foreach"] = True, False
-        if self.distributed and self.reducer is None:
+        # the flat gradient buckets serve a single process too (multi-tensor accumulation, clip and zero_grad on a handful of
+        # kernels); CM_FLAT_GRADS=0 keeps autograd's own per-parameter gradients when nothing is exchanged
+        if self.reducer is None and params and (self.distributed or os.environ.get("CM_FLAT_GRADS", "1") == "1"):
             self.reducer = GradAllReducer(params)
 
     # ---- the loop ---------------------------------------------------------------------------
@@ -91,7 +93,11 @@ class Brain:
             with self._autocast():
                 outputs = self.compute_forward(batch, Stage.TRAIN)
                 loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+            if self.reducer is not None:
+                self.reducer.prepare()                   # gradients arrive by reference, one multi-tensor add per bucket
             (loss / self.grad_accumulation_factor).backward()
+            if self.reducer is not None and not should_step:
+                self.reducer.flush()
         if should_step:
             if self.reducer is not None:
                 self.reducer.finish()

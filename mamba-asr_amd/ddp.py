@@ -18,6 +18,11 @@ in the CPU tests), laid out for 288 GB GPUs on point-to-point links:
     direction: SURVEY.md §5 prices 126 MB at ≈0.4 ms vs ≈2.9 ms), the owner sums its 8 shards in fixed rank order
     (deterministic, unlike a ring whose order depends on the rank's position), and an all-gather returns the sums;
   * gradients may travel as bf16 (halves the per-link bytes; a persistent bf16 staging buffer per bucket) or fp32;
+  * accumulation without a kernel per parameter: ``prepare()`` before a backward detaches the ``.grad``s, so autograd
+    hands each gradient over as the tensor that produced it, the hook collects them per bucket, and ONE multi-tensor add
+    per bucket (``torch._foreach_add_``) folds them into the bucket -- instead of the ~500 in-place adds per micro-batch
+    autograd issues into attached views (3.6 ms of a 89 ms step in rocprofv3's stats); ``flush()`` / ``finish()``
+    re-attach the views for the optimizer.  A backward run without ``prepare()`` accumulates in place as before;
   * ``no_sync()`` skips the exchange on accumulation micro-batches; ``finish()`` waits for the exchange;
     ``zero_grad()`` clears the buckets with one memset each and keeps the views attached (the Brain loop calls it
     in place of ``optimizer.zero_grad(set_to_none=True)``, which would detach them).
@@ -50,6 +55,20 @@ class _Bucket:
         self.pending = len(params)
         self.work = None
         self.launched = False
+        self.inc_v: List[torch.Tensor] = []                               # views / gradients waiting for the multi-tensor add
+        self.inc_g: List[torch.Tensor] = []
+
+    def fold(self):
+        """Add the collected gradients into the bucket: one multi-tensor launch for the fp32 ones."""
+        if not self.inc_g:
+            return
+        same = [(v, g) for v, g in zip(self.inc_v, self.inc_g) if g.dtype == v.dtype and g.device == v.device]
+        if same:
+            torch._foreach_add_([v for v, _ in same], [g for _, g in same])
+        for v, g in zip(self.inc_v, self.inc_g):
+            if g.dtype != v.dtype or g.device != v.device:
+                v.add_(g.to(device=v.device, dtype=v.dtype))
+        self.inc_v, self.inc_g = [], []
 
     def attach(self):
         """(Re-)point every parameter's .grad at its view; a gradient that autograd allocated elsewhere (after a
@@ -81,6 +100,7 @@ class GradAllReducer:
         if self.algo not in ("allreduce", "mesh"):
             raise ValueError(f"algo {self.algo!r}: 'allreduce' or 'mesh'")
         self._sync = True
+        self._detached = False
         # a single rank has nothing to exchange; ``always_exchange`` runs the collectives anyway (world-1 smoke of the
         # RCCL path on a one-GPU box)
         self.active = self.world > 1 or (always_exchange and dist.is_initialized())
@@ -114,13 +134,20 @@ class GradAllReducer:
     # ---- autograd side -------------------------------------------------------------------
     def _hook(self, p):
         b, v = self._owner[p], self._view[p]
-        if p.grad.data_ptr() != v.data_ptr():      # foreign zero_grad(set_to_none=True): fold in and re-attach
-            v.copy_(p.grad)
-            p.grad = v
+        g = p.grad
+        if g.data_ptr() != v.data_ptr():
+            if self._detached:                     # prepare() ran: autograd handed the gradient over, it joins the bucket's
+                b.inc_v.append(v)                  # multi-tensor add
+                b.inc_g.append(g)
+                p.grad = None
+            else:                                  # foreign zero_grad(set_to_none=True): fold in and re-attach
+                v.copy_(g)
+                p.grad = v
         if not self._sync or not self.active:
             return
         b.pending -= 1
         if b.pending == 0:
+            b.fold()
             self._launch(b)
 
     def _launch(self, b: _Bucket):
@@ -153,6 +180,20 @@ class GradAllReducer:
         b.flat.mul_(1.0 / self.world)                                                      # the mean, one kernel per bucket
 
     # ---- training-loop side ----------------------------------------------------------------
+    def prepare(self):
+        """Call before a backward: detach every ``.grad`` so that autograd passes gradients by reference (no add kernel
+        per parameter); they are folded into the buckets by ``flush()`` / ``finish()`` or when a bucket's exchange starts."""
+        for p in self.params:
+            p.grad = None
+        self._detached = True
+
+    def flush(self):
+        """Call after the backward of an accumulation micro-batch: fold the collected gradients, re-attach the views."""
+        for b in self.buckets:
+            b.fold()
+            b.attach()
+        self._detached = False
+
     @contextlib.contextmanager
     def no_sync(self):
         """Accumulation micro-batch: gradients stay local (the reference's Brain uses DDP.no_sync the same way)."""
@@ -165,14 +206,17 @@ class GradAllReducer:
     def finish(self):
         """Call after backward of a stepping micro-batch: waits for every bucket; gradients then hold the means."""
         if not self.active:
+            self.flush()
             return
         t0 = time.perf_counter()
         for b in self.buckets:
             if not b.launched:                     # parameters of this bucket that produced no gradient this step: their
-                b.attach()                         # slices are zero (zero_grad) and travel as zeros
+                b.fold()                           # slices are zero (zero_grad) and travel as zeros
                 self._launch(b)
             self._complete(b)
+            b.attach()
             b.reset()
+        self._detached = False
         if self.buckets and self.buckets[0].flat.is_cuda:
             torch.cuda.current_stream().synchronize()
         self.exposed_s = time.perf_counter() - t0

@@ -120,3 +120,43 @@ def test_grad_allreduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_flat_buckets_accumulate_by_reference_single_process():
+    """GradAllReducer.prepare() / flush() / finish() without a process group: gradients handed over by reference and folded
+    with one multi-tensor add per bucket equal autograd's own in-place accumulation bit for bit over several micro-batches
+    (same order of additions), the views are re-attached for the optimizer, a parameter that got no gradient in a
+    micro-batch keeps its sum, and a backward run WITHOUT prepare() still accumulates (in place, as before)."""
+    from mamba_asr_amd.ddp import GradAllReducer
+    torch.manual_seed(3)
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(12, 20), torch.nn.GELU(), torch.nn.Linear(20, 7), torch.nn.Linear(7, 3))
+
+    ref, net = make(), make()
+    extra_ref, extra = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(4))      # used in one micro-batch only
+    red = GradAllReducer(list(net.parameters()) + [extra], bucket_mb=0.001)                      # several small buckets
+    assert len(red.buckets) > 1 and not red.active
+    xs = [torch.randn(5, 12) for _ in range(4)]
+    for i, x in enumerate(xs):
+        loss_r = ref(x).square().mean() + (extra_ref.sum() * 0.5 if i == 1 else 0.0)
+        loss_r.backward()
+        loss = net(x).square().mean() + (extra.sum() * 0.5 if i == 1 else 0.0)
+        if i != 2:
+            red.prepare()
+        loss.backward()                                          # micro-batch 2: no prepare(), in-place accumulation
+        if i < 3:
+            red.flush()
+        else:
+            red.finish()
+        for p in list(net.parameters()) + [extra]:
+            assert p.grad is not None and p.grad.data_ptr() == red._view[p].data_ptr()
+    for a, b in zip(ref.parameters(), net.parameters()):
+        assert torch.equal(a.grad, b.grad)
+    assert torch.equal(extra_ref.grad, extra.grad)
+    total = red.clip_grad_norm_(1e9)
+    want = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in list(ref.parameters()) + [extra_ref]]))
+    torch.testing.assert_close(total, want)
+    red.zero_grad()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
