@@ -37,8 +37,20 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 }
 __device__ __forceinline__ float silu(float a) { return a * cm_sigmoid(a); }
 
+// cm_debug_set(18): per-phase s_memtime stamps of one mid-grid workgroup (waves 0 and 3), read back with cm_debug_read_stamps_cx
+__device__ unsigned long long g_cx_stamps[16];
+__device__ __forceinline__ bool cm_ksplit_ok(int stamp) { return stamp != 2; }     // cm_debug_set(19): one wave per direction (A / B)
+__device__ __forceinline__ unsigned long long cx_now() {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 template <int TT>
-__global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile) {
+__global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile, const int stamp = 0) {
+    const bool st_wg = stamp == 1 && blockIdx.x == gridDim.x / 2 + 3;
+    unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
+    if (st_wg) ts_[0] = cx_now();
     constexpr int TH = TT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int E = p.dim, T = p.seqlen;
@@ -62,60 +74,14 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     };
     const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bs, x_ts), fr = rsrc(p.y_fwd, p.yf_bs, yf_ts), br = rsrc(p.y_bwd, p.yb_bs, yb_ts);
 
-    // ---- phase 1: conv + SiLU, both directions.  thread = (4-channel group, half of the tile's steps)
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int ts = t0 + TH * half;                                // first step of this thread (wave-uniform)
-    for (int cg = tid & 127; cg < E / 4; cg += 128) {
-        const int c0 = cg * 4;
-        u32x2 raw[TH + 2 * (W - 1)];                              // rows ts-3 .. ts+TH+2, all loads issued first
-#pragma unroll
-        for (int r = 0; r < TH + 2 * (W - 1); ++r)
-            raw[r] = __builtin_amdgcn_raw_buffer_load_b64(xr, c0 * 2, (ts - (W - 1) + r) * x_ts, 0);
-        float wf[4][W], wb[4][W], bf[4], bb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 f = *reinterpret_cast<const float4 *>(p.weight_f + (c0 + j) * W);
-            const float4 g = *reinterpret_cast<const float4 *>(p.weight_b + (c0 + j) * W);
-            wf[j][0] = f.x; wf[j][1] = f.y; wf[j][2] = f.z; wf[j][3] = f.w;
-            wb[j][0] = g.x; wb[j][1] = g.y; wb[j][2] = g.z; wb[j][3] = g.w;
-            bf[j] = p.bias_f ? p.bias_f[c0 + j] : 0.f;
-            bb[j] = p.bias_b ? p.bias_b[c0 + j] : 0.f;
-        }
-        auto elem = [&](int r, int j) -> float {
-            const uint32_t w2 = j < 2 ? raw[r][0] : raw[r][1];
-            return (j & 1) ? cm_bf16_hi(w2) : cm_bf16_lo(w2);
-        };
-#pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            float of[4], ob[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float af = bf[j], ab = bb[j];
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    af = fmaf(wf[j][k], elem(i + k, j), af);                       // x[t-(W-1)+k]
-                    ab = fmaf(wb[j][k], elem(i + 2 * (W - 1) - k, j), ab);         // x[t+(W-1)-k]
-                }
-                of[j] = silu(af);
-                ob[j] = silu(ab);
-            }
-            const u32x2 pf = {pack2(of[0], of[1]), pack2(of[2], of[3])};
-            const u32x2 pb = {pack2(ob[0], ob[1]), pack2(ob[2], ob[3])};
-            const int tl = TH * half + i;
-            *reinterpret_cast<u32x2 *>(ut[0] + tl * XS + c0) = pf;
-            *reinterpret_cast<u32x2 *>(ut[1] + tl * XS + c0) = pb;
-            __builtin_amdgcn_raw_buffer_store_b64(pf, fr, c0 * 2, (ts + i) * yf_ts, 0);     // steps >= T: out of range, dropped
-            __builtin_amdgcn_raw_buffer_store_b64(pb, br, c0 * 2, (ts + i) * yb_ts, 0);
-        }
-    }
-    cm_lds_barrier();                                             // the u stores to HBM stay in flight under phase 2
-
-    // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c]; one wave per direction (48 MFMAs)
-    if (wave >= 2) return;
-    const int dir = wave;
+    // ---- phase 2's operands, set up first: wave = (direction, K half); the 32-step build requests its weights now
+    constexpr bool EARLY = TT == 32;
     constexpr int NTL = TT / 16;                                  // token tiles per workgroup
     const int l15 = lane & 15, lq = lane >> 4;
     const int nks = E / 32;
+    const int dir = wave & 1, kh = wave >> 1;
+    const bool ksplit = (nks & 1) == 0 && cm_ksplit_ok(stamp);
+    const int ks_lo = ksplit ? kh * (nks / 2) : 0, ks_hi = ksplit ? ks_lo + nks / 2 : (kh == 0 ? nks : 0);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(dir ? p.wx_b : p.wx_f), 0, NP * E * 2, 0x00020000);
     const int vl = lane * 16;
@@ -125,19 +91,112 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
         for (int mt = 0; mt < 3; ++mt)
             dst[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, vl, (mt * nks + ks) * 1024, 0));
     };
+    bool wq_requested = !EARLY;
+
+    // ---- phase 1: conv + SiLU, both directions.  thread = (4-channel group, half of the tile's steps)
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ts = t0 + TH * half;                                // first step of this thread (wave-uniform)
+    for (int cg = tid & 127; cg < E / 4; cg += 128) {
+        const int c0 = cg * 4;
+        u32x2 raw[TH + 2 * (W - 1)];                              // rows ts-3 .. ts+TH+2, all loads issued first
 #pragma unroll
-    for (int s = 0; s < PF; ++s) wload(s, wq[s]);                 // past-the-end fragments read as zeros (buffer bounds)
+        for (int r = 0; r < TH + 2 * (W - 1); ++r)
+            raw[r] = __builtin_amdgcn_raw_buffer_load_b64(xr, c0 * 2, (ts - (W - 1) + r) * x_ts, 0);
+        if (!wq_requested) {                                      // behind the rows (HBM) in the in-order return queue: phase 1 waits
+            wq_requested = true;                                  // for the rows only, the L2-resident weights land during it
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+                if (ks_lo + s < ks_hi) wload(ks_lo + s, wq[s]);
+        }
+        if (st_wg) ts_[1] = cx_now();                             // rows have arrived
+        // two channel PAIRS per thread: a staged dword is one pair, so taps, bias and SiLU run as v_pk_*_f32 on (lo, hi),
+        // and every staged row is widened to fp32 once, when it enters the 7-row window (the scalar form widened each
+        // element at each of its 8 uses: as many shifts as multiply-adds)
+        f32x2 wf[2][W], wb[2][W], bf[2], bb[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const float4 f0 = *reinterpret_cast<const float4 *>(p.weight_f + (c0 + 2 * pr) * W);
+            const float4 f1 = *reinterpret_cast<const float4 *>(p.weight_f + (c0 + 2 * pr + 1) * W);
+            const float4 g0 = *reinterpret_cast<const float4 *>(p.weight_b + (c0 + 2 * pr) * W);
+            const float4 g1 = *reinterpret_cast<const float4 *>(p.weight_b + (c0 + 2 * pr + 1) * W);
+            wf[pr][0] = f32x2{f0.x, f1.x}; wf[pr][1] = f32x2{f0.y, f1.y}; wf[pr][2] = f32x2{f0.z, f1.z}; wf[pr][3] = f32x2{f0.w, f1.w};
+            wb[pr][0] = f32x2{g0.x, g1.x}; wb[pr][1] = f32x2{g0.y, g1.y}; wb[pr][2] = f32x2{g0.z, g1.z}; wb[pr][3] = f32x2{g0.w, g1.w};
+            bf[pr] = p.bias_f ? f32x2{p.bias_f[c0 + 2 * pr], p.bias_f[c0 + 2 * pr + 1]} : f32x2{0.f, 0.f};
+            bb[pr] = p.bias_b ? f32x2{p.bias_b[c0 + 2 * pr], p.bias_b[c0 + 2 * pr + 1]} : f32x2{0.f, 0.f};
+        }
+        auto widen = [&](int r, int pr) -> f32x2 { return f32x2{cm_bf16_lo(raw[r][pr]), cm_bf16_hi(raw[r][pr])}; };
+        auto silu2 = [](f32x2 a) -> f32x2 {                       // a / (1 + 2^(-a log2 e))
+            const f32x2 e = a * f32x2{-CM_LOG2E, -CM_LOG2E};
+            const f32x2 d = f32x2{cm_exp2(e.x), cm_exp2(e.y)} + f32x2{1.0f, 1.0f};
+            return a * f32x2{cm_rcp(d.x), cm_rcp(d.y)};
+        };
+        f32x2 xw[2 * (W - 1) + 1][2];                             // rows i .. i+6 of the window, [row][pair]
+#pragma unroll
+        for (int r = 0; r < 2 * (W - 1); ++r) { xw[r][0] = widen(r, 0); xw[r][1] = widen(r, 1); }
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            xw[2 * (W - 1)][0] = widen(i + 2 * (W - 1), 0);
+            xw[2 * (W - 1)][1] = widen(i + 2 * (W - 1), 1);
+            u32x2 pf, pb;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x2 af = bf[pr], ab = bb[pr];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    af = __builtin_elementwise_fma(wf[pr][k], xw[k][pr], af);                     // x[t-(W-1)+k]
+                    ab = __builtin_elementwise_fma(wb[pr][k], xw[2 * (W - 1) - k][pr], ab);       // x[t+(W-1)-k]
+                }
+                const f32x2 of = silu2(af), ob = silu2(ab);
+                pf[pr] = pack2(of.x, of.y);
+                pb[pr] = pack2(ob.x, ob.y);
+            }
+            const int tl = TH * half + i;
+            *reinterpret_cast<u32x2 *>(ut[0] + tl * XS + c0) = pf;
+            *reinterpret_cast<u32x2 *>(ut[1] + tl * XS + c0) = pb;
+            __builtin_amdgcn_raw_buffer_store_b64(pf, fr, c0 * 2, (ts + i) * yf_ts, 0);     // steps >= T: out of range, dropped
+            __builtin_amdgcn_raw_buffer_store_b64(pb, br, c0 * 2, (ts + i) * yb_ts, 0);
+#pragma unroll
+            for (int r = 0; r < 2 * (W - 1); ++r) { xw[r][0] = xw[r + 1][0]; xw[r][1] = xw[r + 1][1]; }   // slide (register renaming)
+        }
+    }
+    if (!wq_requested) {                                          // lanes without a channel group (dim < 512) skipped the loop
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+            if (ks_lo + s < ks_hi) wload(ks_lo + s, wq[s]);
+    }
+    if (st_wg) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      // phase 1 issued (stores still in flight)
+        ts_[2] = t;
+    }
+    cm_lds_barrier();                                             // the u stores to HBM stay in flight under phase 2
+    if (st_wg) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        ts_[3] = t;
+        if (wave == 3 && lane == 0) { for (int i = 0; i < 4; ++i) g_cx_stamps[8 + i] = ts_[i]; }
+    }
+
+    // ---- phase 2: x_dbl[token][dir*48 + f] = sum_c W_dir[f][c] u_dir[token][c].  All four waves: wave = (direction, K half);
+    // the halves meet through LDS (the token tiles are dead by then).  In-kernel stamps of the version with one wave per
+    // direction: phase 1 9.8 k ticks, phase 2 10.7 k (96 MFMAs = 1.5 k of them: the rest was the wave waiting on its own
+    // 48 KB weight stream from L2) -- so the weights of the 32-step build are requested BEFORE phase 1 (96 VGPRs held across
+    // it, 232 in all) and phase 2 is MFMAs and fragment reads only.
+    const uint16_t *frag = ut[dir] + l15 * XS + lq * 8;
     f32x4 acc[NTL][3];
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint16_t *frag = ut[dir] + l15 * XS + lq * 8;
-    for (int ks0 = 0; ks0 < nks; ks0 += PF) {
+    if (!EARLY) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) wload(ks_lo + s, wq[s]);     // past-the-end fragments read as zeros (buffer bounds)
+    }
+    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const int ks = ks0 + s;
-            if (ks < nks) {
+            if (ks < ks_hi) {
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
                     const bf16x8 tok = *reinterpret_cast<const bf16x8 *>(frag + nt * 16 * XS + ks * 32);
@@ -145,9 +204,32 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
                     for (int mt = 0; mt < 3; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][mt], tok, acc[nt][mt], 0, 0, 0);
                 }
-                wload(ks + PF, wq[s]);
+                if (ks + PF < ks_hi) wload(ks + PF, wq[s]);
             }
         }
+    }
+    if (st_wg) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");      // MFMA loop issued
+        ts_[4] = t;
+    }
+    if (ksplit) {
+        cm_lds_barrier();                                         // every wave is done with the token tiles
+        float *xch = reinterpret_cast<float *>(smem) + (dir * 64 + lane) * (NTL * 12);
+        if (kh == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) *reinterpret_cast<f32x4 *>(xch + (nt * 3 + mt) * 4) = acc[nt][mt];
+        }
+        cm_lds_barrier();
+        if (kh == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) acc[nt][mt] += *reinterpret_cast<const f32x4 *>(xch + (nt * 3 + mt) * 4);
+    } else if (kh == 1) {
+        return;
     }
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt) {
@@ -158,6 +240,10 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
             for (int mt = 0; mt < 3; ++mt)
                 *reinterpret_cast<uint2 *>(xo + mt * 16) = uint2{pack2(acc[nt][mt][0], acc[nt][mt][1]), pack2(acc[nt][mt][2], acc[nt][mt][3])};
         }
+    }
+    if (st_wg && wave == 0) {
+        ts_[5] = cx_now();                                        // everything of this wave has landed
+        if (lane == 0) { for (int i = 0; i < 6; ++i) g_cx_stamps[i] = ts_[i]; }
     }
 }
 
@@ -176,11 +262,15 @@ int launch_cx(const cm_conv_xproj_args &a) {
     }
     const int ntile = (a.seqlen + TT - 1) / TT;
     CM_REQUIRE((long)ntile * a.batch < (1L << 31), CM_EINVAL, "conv_xproj: grid too large");
-    hipLaunchKernelGGL(conv_xproj_kernel<TT>, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile);
+    hipLaunchKernelGGL(conv_xproj_kernel<TT>, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile, cm_debug_get() == 18 ? 1 : (cm_debug_get() == 19 ? 2 : 0));
     return cm_launch_status("cm_conv_xproj");
 }
 
 }  // namespace
+
+extern "C" int cm_debug_read_stamps_cx(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cx_stamps), sizeof(unsigned long long) * 16);
+}
 
 extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "conv_xproj: args is NULL");
