@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     };
     const int f0 = wave * 64 + lq * 4;
     float r[4][4][4];                                             // epilogue: [token tile][feature tile][4 features]
-    // one hidden slab; the last one is peeled (LAST) so that the residual rows it prefetches are not live in the loop
+    // one hidden slab; the last one is peeled (LAST): it does not request the next slab's weights
     auto slab = [&](const int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         f32x4 acc1[4][4];
@@ -211,17 +211,6 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             }
         }
         lds_barrier();
-        if constexpr (LAST) {                                     // residual rows for the epilogue: in flight under GEMM 2
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int tok = min(t0 + th * 64 + nb * 16 + l15, M - 1);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const float4 xv = load_x4(tok, f0 + mb * 16);
-                    r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
-                }
-            }
-        }
         // GEMM 2: 64 output features x 64 tokens, K = this slab
         read_frags(hfrag, 0, bfa);
 #pragma unroll
@@ -241,6 +230,19 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     };
     for (int c = 0; c + 1 < nch; ++c) slab(c, std::false_type{});
     slab(nch - 1, std::true_type{});
+    // Residual rows for the epilogue, requested AFTER the last GEMM.  Requested before it (to travel under its MFMAs) they sat in
+    // front of its weight fragments in the in-order return queue: in-kernel stamps showed that GEMM taking 10.8 k ticks
+    // against 3-4 k for the others (profiles/r02/ffn_stamps_and_variants.log); 120 / 108 / 105 -> 110 / 103 / 100 us for the
+    // second FFN of a layer, 12.52 -> 12.44 ms per step.
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int tok = min(t0 + th * 64 + nb * 16 + l15, M - 1);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 xv = load_x4(tok, f0 + mb * 16);
+            r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
+        }
+    }
 
     // ---- epilogue: r = xin + alpha (acc2 + b2); optional LN1 -> stream; optional LN2 -> h_out.
     // Lane holds token nb*16 + l15, features wave*64 + mb*16 + lq*4 + j.
