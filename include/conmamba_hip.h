@@ -290,10 +290,14 @@ typedef struct cm_conv_xproj_args {
     int32_t batch, seqlen, dim, width;
     const void  *x;
     const float *weight_f, *bias_f, *weight_b, *bias_b;   /* (dim, 4) / (dim); biases may be NULL */
-    const void  *wx_f, *wx_b;                             /* packed (48, dim) bf16                */
+    const void  *wx_f, *wx_b;                             /* packed (dt_pad + 32, dim) bf16       */
     void *y_fwd, *y_bwd, *xdbl;
     int64_t x_bs, x_ts, yf_bs, yf_ts, yb_bs, yb_ts, xdbl_bs, xdbl_ts;
     void *stream;
+    int32_t dt_pad;                                       /* 0 / 16: x_dbl rows [dt16 | B | C] per direction (96 columns in all);
+                                                             32: [dt32 | B | C] (128 columns), the layout cm_scan_cl_fwd's xdbl
+                                                             mode takes for 16 < dt_rank <= 32                                   */
+    int32_t pad_;
 } cm_conv_xproj_args;
 
 int cm_conv_xproj(const cm_conv_xproj_args *args);

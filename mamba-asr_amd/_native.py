@@ -91,7 +91,7 @@ class ConvXprojArgs(C.Structure):
         ("x", vp), ("weight_f", fp), ("bias_f", fp), ("weight_b", fp), ("bias_b", fp), ("wx_f", vp), ("wx_b", vp),
         ("y_fwd", vp), ("y_bwd", vp), ("xdbl", vp),
         ("x_bs", i64), ("x_ts", i64), ("yf_bs", i64), ("yf_ts", i64), ("yb_bs", i64), ("yb_ts", i64),
-        ("xdbl_bs", i64), ("xdbl_ts", i64), ("stream", vp),
+        ("xdbl_bs", i64), ("xdbl_ts", i64), ("stream", vp), ("dt_pad", i32), ("pad_", i32),
     ]
 
 

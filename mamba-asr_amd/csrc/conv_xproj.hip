@@ -25,7 +25,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // TWO token tiles (at TT = 16 the 96 KB of weights per workgroup are more L2 traffic than the kernel's HBM bytes) and reads
 // 22 rows per 16 outputs instead of 14 per 8; its LDS tiles (67 KB) leave two workgroups per CU.
 constexpr int W = 4;            // conv width
-constexpr int NP = 48;          // x_dbl columns per direction
 constexpr int PF = 8;           // weight-fragment ring depth
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -46,12 +45,14 @@ __device__ __forceinline__ unsigned long long cx_now() {
     return t;
 }
 
-template <int TT>
-__global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile, const int stamp = 0) {
+// NB: 16-column bands of x_dbl per direction: 3 = [dt16 | B | C], 4 = [dt32 | B | C] (dt_rank 17..32: the S2S-large encoder)
+template <int TT, int NB>
+__global__ __launch_bounds__(256, (TT == 16 && NB == 3) ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile, const int stamp = 0) {
     const bool st_wg = stamp == 1 && blockIdx.x == gridDim.x / 2 + 3;
     unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
     if (st_wg) ts_[0] = cx_now();
     constexpr int TH = TT / 2;
+    constexpr int NP = NB * 16;                                   // x_dbl columns per direction
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int E = p.dim, T = p.seqlen;
     const int XS = E + 16;                                        // LDS row stride in bf16 elements
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bs, x_ts), fr = rsrc(p.y_fwd, p.yf_bs, yf_ts), br = rsrc(p.y_bwd, p.yb_bs, yb_ts);
 
     // ---- phase 2's operands, set up first: wave = (direction, K half); the 32-step build requests its weights now
-    constexpr bool EARLY = TT == 32;
+    constexpr bool EARLY = TT == 32 || NB == 4;              // builds with a 256-VGPR budget
     constexpr int NTL = TT / 16;                                  // token tiles per workgroup
     const int l15 = lane & 15, lq = lane >> 4;
     const int nks = E / 32;
@@ -85,10 +86,10 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(dir ? p.wx_b : p.wx_f), 0, NP * E * 2, 0x00020000);
     const int vl = lane * 16;
-    bf16x8 wq[PF][3];
-    auto wload = [&](int ks, bf16x8(&dst)[3]) {                   // fragment (band mt, k-tile ks) = 1 KB at (mt*nks + ks)*1024
+    bf16x8 wq[PF][NB];
+    auto wload = [&](int ks, bf16x8(&dst)[NB]) {                   // fragment (band mt, k-tile ks) = 1 KB at (mt*nks + ks)*1024
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
+        for (int mt = 0; mt < NB; ++mt)
             dst[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, vl, (mt * nks + ks) * 1024, 0));
     };
     bool wq_requested = !EARLY;
@@ -183,11 +184,11 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     // 48 KB weight stream from L2) -- so the weights of the 32-step build are requested BEFORE phase 1 (96 VGPRs held across
     // it, 232 in all) and phase 2 is MFMAs and fragment reads only.
     const uint16_t *frag = ut[dir] + l15 * XS + lq * 8;
-    f32x4 acc[NTL][3];
+    f32x4 acc[NTL][NB];
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < NB; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!EARLY) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) wload(ks_lo + s, wq[s]);     // past-the-end fragments read as zeros (buffer bounds)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
                 for (int nt = 0; nt < NTL; ++nt) {
                     const bf16x8 tok = *reinterpret_cast<const bf16x8 *>(frag + nt * 16 * XS + ks * 32);
 #pragma unroll
-                    for (int mt = 0; mt < 3; ++mt)
+                    for (int mt = 0; mt < NB; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][mt], tok, acc[nt][mt], 0, 0, 0);
                 }
                 if (ks + PF < ks_hi) wload(ks + PF, wq[s]);
@@ -215,19 +216,19 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     }
     if (ksplit) {
         cm_lds_barrier();                                         // every wave is done with the token tiles
-        float *xch = reinterpret_cast<float *>(smem) + (dir * 64 + lane) * (NTL * 12);
+        float *xch = reinterpret_cast<float *>(smem) + (dir * 64 + lane) * (NTL * NB * 4);
         if (kh == 1) {
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) *reinterpret_cast<f32x4 *>(xch + (nt * 3 + mt) * 4) = acc[nt][mt];
+                for (int mt = 0; mt < NB; ++mt) *reinterpret_cast<f32x4 *>(xch + (nt * NB + mt) * 4) = acc[nt][mt];
         }
         cm_lds_barrier();
         if (kh == 1) return;
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) acc[nt][mt] += *reinterpret_cast<const f32x4 *>(xch + (nt * 3 + mt) * 4);
+            for (int mt = 0; mt < NB; ++mt) acc[nt][mt] += *reinterpret_cast<const f32x4 *>(xch + (nt * NB + mt) * 4);
     } else if (kh == 1) {
         return;
     }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
         if (t < T) {
             uint16_t *xo = reinterpret_cast<uint16_t *>(p.xdbl) + (int64_t)b * p.xdbl_bs + (int64_t)t * p.xdbl_ts + dir * NP + lq * 4;
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt)
+            for (int mt = 0; mt < NB; ++mt)
                 *reinterpret_cast<uint2 *>(xo + mt * 16) = uint2{pack2(acc[nt][mt][0], acc[nt][mt][1]), pack2(acc[nt][mt][2], acc[nt][mt][3])};
         }
     }
@@ -247,12 +248,12 @@ __global__ __launch_bounds__(256, TT == 16 ? 4 : 2) void conv_xproj_kernel(const
     }
 }
 
-template <int TT>
+template <int TT, int NB>
 int launch_cx(const cm_conv_xproj_args &a) {
     const size_t smem = (size_t)2 * TT * (a.dim + 16) * sizeof(uint16_t);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_xproj_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_xproj_kernel<TT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("conv_xproj: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -262,7 +263,7 @@ int launch_cx(const cm_conv_xproj_args &a) {
     }
     const int ntile = (a.seqlen + TT - 1) / TT;
     CM_REQUIRE((long)ntile * a.batch < (1L << 31), CM_EINVAL, "conv_xproj: grid too large");
-    hipLaunchKernelGGL(conv_xproj_kernel<TT>, dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile, cm_debug_get() == 18 ? 1 : (cm_debug_get() == 19 ? 2 : 0));
+    hipLaunchKernelGGL((conv_xproj_kernel<TT, NB>), dim3((unsigned)(ntile * a.batch)), dim3(256), smem, reinterpret_cast<hipStream_t>(a.stream), a, ntile, cm_debug_get() == 18 ? 1 : (cm_debug_get() == 19 ? 2 : 0));
     return cm_launch_status("cm_conv_xproj");
 }
 
@@ -286,5 +287,10 @@ extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
                CM_EALIGN, "conv_xproj: tensors must be 8-byte aligned (weights 16) with strides that are multiples of 4 elements");
     // 32-step tiles when the LDS tiles fit twice per CU and the sequence is long enough to fill the chip with them
     const bool wide = cm_debug_get() != 16 && (size_t)2 * 32 * (a.dim + 16) * 2 <= 72 * 1024 && (long)a.batch * ((a.seqlen + 31) / 32) >= 512;
-    return wide ? launch_cx<32>(a) : launch_cx<16>(a);
+    CM_REQUIRE(a.dt_pad == 0 || a.dt_pad == 16 || a.dt_pad == 32, CM_EUNSUPPORTED, "conv_xproj: dt_pad %d (16 or 32)", a.dt_pad);
+    if (a.dt_pad == 32) {
+        CM_REQUIRE((size_t)2 * 16 * (a.dim + 16) * 2 <= 80 * 1024, CM_EUNSUPPORTED, "conv_xproj: dim %d too wide for 64-column rows", a.dim);
+        return wide ? launch_cx<32, 4>(a) : launch_cx<16, 4>(a);
+    }
+    return wide ? launch_cx<32, 3>(a) : launch_cx<16, 3>(a);
 }

@@ -77,10 +77,10 @@ class _LayerCache:
                 xr[RW * i:RW * i + R, cols] = wsrc[:R]
                 xr[RW * i + pad:RW * (i + 1), cols] = wsrc[R:]
             self.x_proj_rows = xr
-            # per-direction (48, E) images for cm_conv_xproj (conv + x_proj in one kernel, bf16)
+            # per-direction (RW, E) images for cm_conv_xproj (conv + x_proj in one kernel, bf16)
             self.wx_packed = None
-            if RW == 48 and dtype == torch.bfloat16 and m.d_inner % 32 == 0 and xr.is_cuda and m.d_conv == 4:
-                self.wx_packed = [ops.PackedWeight(xr[48 * i:48 * (i + 1), i * m.d_inner:(i + 1) * m.d_inner].contiguous())
+            if dtype == torch.bfloat16 and m.d_inner % 32 == 0 and m.d_inner <= 2048 and xr.is_cuda and m.d_conv == 4:
+                self.wx_packed = [ops.PackedWeight(xr[RW * i:RW * (i + 1), i * m.d_inner:(i + 1) * m.d_inner].contiguous())
                                   for i in range(2)]
             for d_, dtp in zip(self.dirs, (m.dt_proj, m.dt_proj_b)):
                 d_["dt_w16"] = ops.pad_dt_weight(dtp.weight.detach().to(dtype))      # dtype-rounded like the reference's GEMM operand

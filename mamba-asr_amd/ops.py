@@ -426,25 +426,29 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None):
 
 def conv_xproj(x, weight_f, bias_f, weight_b, bias_b, wx_f, wx_b, out_f, out_b, xdbl=None):
     """Both directions' depthwise conv + SiLU and x_proj GEMMs in one kernel (cm_conv_xproj, bf16).
-    x (batch, seqlen, dim) view; conv weights (dim, 4) fp32; wx_f / wx_b PackedWeight of the (48, dim) re-rowed x_proj
-    weights [dt16 | B | C]; out_f / out_b (batch, seqlen, dim) views.  Returns xdbl (batch, seqlen, 96) bf16."""
+    x (batch, seqlen, dim) view; conv weights (dim, 4) fp32; wx_f / wx_b PackedWeight of the (P + 32, dim) re-rowed x_proj
+    weights [dt P | B | C], P = 16, or 32 for 16 < dt_rank <= 32; out_f / out_b (batch, seqlen, dim) views.
+    Returns xdbl (batch, seqlen, 2 * (P + 32)) bf16."""
     _dev_check(x, weight_f, bias_f, weight_b, bias_b, out_f, out_b)
     _rows_ok(x, "x"), _rows_ok(out_f, "out_f"), _rows_ok(out_b, "out_b")
     b, l, d = x.shape
     if x.dtype != torch.bfloat16 or out_f.dtype != torch.bfloat16 or out_b.dtype != torch.bfloat16:
         raise RuntimeError("conv_xproj: bf16 only")
-    if wx_f.shape != (48, d) or wx_b.shape != (48, d):
-        raise RuntimeError("conv_xproj: wx must be PackedWeight of shape (48, dim)")
+    rw = wx_f.shape[0]
+    if rw not in (48, 64) or wx_f.shape != (rw, d) or wx_b.shape != (rw, d):
+        raise RuntimeError("conv_xproj: wx must be PackedWeight of shape (48 | 64, dim)")
     wf, bf, wb, bb = _f32c(weight_f), _f32c(bias_f), _f32c(weight_b), _f32c(bias_b)
     if xdbl is None:
-        xdbl = torch.empty((b, l, 96), dtype=torch.bfloat16, device=x.device)
+        xdbl = torch.empty((b, l, 2 * rw), dtype=torch.bfloat16, device=x.device)
+    elif xdbl.shape != (b, l, 2 * rw) or xdbl.dtype != torch.bfloat16:
+        raise RuntimeError(f"conv_xproj: xdbl must be bf16 (batch, seqlen, {2 * rw})")
     a = N.ConvXprojArgs()
     a.batch, a.seqlen, a.dim, a.width = b, l, d, wf.shape[1]
     a.x, a.weight_f, a.bias_f, a.weight_b, a.bias_b = _ptr(x), _ptr(wf), _ptr(bf), _ptr(wb), _ptr(bb)
     a.wx_f, a.wx_b, a.y_fwd, a.y_bwd, a.xdbl = _ptr(wx_f.data), _ptr(wx_b.data), _ptr(out_f), _ptr(out_b), _ptr(xdbl)
     a.x_bs, a.x_ts, a.yf_bs, a.yf_ts = x.stride(0), x.stride(1), out_f.stride(0), out_f.stride(1)
     a.yb_bs, a.yb_ts, a.xdbl_bs, a.xdbl_ts = out_b.stride(0), out_b.stride(1), xdbl.stride(0), xdbl.stride(1)
-    a.stream = _stream()
+    a.stream, a.dt_pad = _stream(), rw - 32
     _launch("cm_conv_xproj", N.lib().cm_conv_xproj, a, units=b * l)
     return xdbl
 

@@ -364,8 +364,9 @@ def test_scan_rows_time_chunks(ops, shape, chunks, dtype, rank):
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 512), (2, 5, 96), (1, 33, 1024), (16, 1000, 512), (40, 403, 288)])
-def test_conv_xproj(ops, shape):
-    """cm_conv_xproj == cm_conv_cl_fwd (bit-exact u) and x_dbl rows == u @ Wx^T computed in fp32 from the bf16 u and
+@pytest.mark.parametrize("rw", [48, 64])
+def test_conv_xproj(ops, shape, rw):
+    """(rw: x_dbl rows [dt16 | B | C] or, for 16 < dt_rank <= 32, [dt32 | B | C].)  cm_conv_xproj == cm_conv_cl_fwd (bit-exact u) and x_dbl rows == u @ Wx^T computed in fp32 from the bf16 u and
     bf16 weights (the products the MFMA forms), within bf16 output rounding; x a column slice of a wider [x | z].
     The last two shapes are large enough for the 32-step tiles (ragged last tile in the second); the 16-step tiles on
     the same input must give the same bits."""
@@ -375,7 +376,7 @@ def test_conv_xproj(ops, shape):
     x = xz[:, :, :e]
     wf, wb = torch.randn(e, 4, generator=gen).to(DEV) * 0.5, torch.randn(e, 4, generator=gen).to(DEV) * 0.5
     bf, bb = torch.randn(e, generator=gen).to(DEV) * 0.1, torch.randn(e, generator=gen).to(DEV) * 0.1
-    wx = [(torch.randn(48, e, generator=gen) * 0.1).bfloat16().to(DEV) for _ in range(2)]
+    wx = [(torch.randn(rw, e, generator=gen) * 0.1).bfloat16().to(DEV) for _ in range(2)]
     ucat = torch.zeros(b, l, 2 * e, dtype=torch.bfloat16, device=DEV)
     xdbl = ops.conv_xproj(x, wf, bf, wb, bb, ops.PackedWeight(wx[0]), ops.PackedWeight(wx[1]), out_f=ucat[:, :, :e], out_b=ucat[:, :, e:])
     rf, rb = ops.conv_cl_fwd(x, wf, bf, wb, bb, True)
@@ -385,7 +386,8 @@ def test_conv_xproj(ops, shape):
     close(rf.float(), ref, 1.6e-2, 1e-2)
     for i, u in enumerate((rf, rb)):
         want = u.float() @ wx[i].float().t()
-        close(xdbl[:, :, 48 * i:48 * (i + 1)].float(), want, 1.6e-2, 2e-2)
+        close(xdbl[:, :, rw * i:rw * (i + 1)].float(), want, 1.6e-2, 2e-2)
+    assert xdbl.shape == (b, l, 2 * rw)
     if b * ((l + 31) // 32) >= 512:
         from mamba_asr_amd import _native
         u16 = torch.zeros_like(ucat)
