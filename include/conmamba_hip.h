@@ -632,8 +632,14 @@ typedef struct cm_ffn_args {
     float       *x_out;                 /* (rows, 256) fp32 or NULL                          */
     void        *h_out;                 /* (rows, 256) h_dtype or NULL                       */
     float add_scale, alpha, pre_eps, n1_eps, n2_eps;
-    int32_t pad_;
+    int32_t proj_dim;                   /* rows of proj_w (a multiple of 256, <= 4096); 0 without a projection            */
     void *stream;
+    /* optional: the Linear that consumes h, applied to the tile in the same kernel -- the BiMamba in_proj behind the
+       layer's first feed-forward module (reference bimamba.py:192-200):  proj_out = LN2(r) @ proj_w^T (+ proj_b), bf16;
+       h_out must be NULL then (h is not stored) */
+    const void  *proj_w;                /* (proj_dim, 256) bf16, cm_ffn_pack_weights' image                                */
+    const float *proj_b;                /* (proj_dim) fp32 or NULL                                                          */
+    void        *proj_out;              /* (rows, proj_dim) bf16                                                            */
 } cm_ffn_args;
 
 int cm_ffn_fused(const cm_ffn_args *args);

@@ -198,7 +198,7 @@ class FfnArgs(C.Structure):
         ("x", fp), ("addend", vp), ("pre_g", fp), ("pre_b", fp), ("w1", vp), ("b1", fp), ("w2", vp), ("b2", fp),
         ("n1_g", fp), ("n1_b", fp), ("n2_g", fp), ("n2_b", fp), ("x_out", fp), ("h_out", vp),
         ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
-        ("pad_", i32), ("stream", vp),
+        ("proj_dim", i32), ("stream", vp), ("proj_w", vp), ("proj_b", fp), ("proj_out", vp),
     ]
 
 

@@ -47,7 +47,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 // VAR (cm_debug_set, timing only): 1 = scalar GELU (cm_gelu_bf16 per element; 108-110 us vs 99-100 us packed at 64k rows), 2 = no GELU, 3 = no weight stream after the first fill,
 // 4 = no token-fragment reads after the first, 5 = 2 + 3 + 4.  (Starting the workgroups of the second occupancy slot
 // 3.4 / 10 us late, so that a CU's two workgroups are in different phases, was also tried: no effect.)
-template <bool ADD, int VAR = 0>
+// PROJ: the Linear that consumes h (the BiMamba in_proj after the layer's first feed-forward module, reference
+// bimamba.py:192-200) runs on the tile before it leaves the CU: proj_out = LN2(r) @ proj_w^T, h itself is not stored.
+template <bool ADD, int VAR = 0, bool PROJ = false>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
         }
     };
     if (p.n1_g) layer_norm(p.n1_g, p.n1_b, p.n1_eps);
-    if (p.x_out) {
+    if (VAR == 26 && p.x_out) {                                   // timing variant: 16-byte pieces of 16 rows per store instruction
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const int tok = t0 + th * 64 + nb * 16 + l15;
@@ -322,6 +324,101 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                         make_float4(r[nb][mb][0], r[nb][mb][1], r[nb][mb][2], r[nb][mb][3]);
             }
         }
+    } else if (p.x_out) {
+        // The stream rows leave through LDS (both token tiles are dead: 64 rows x 1040 bytes over xn + hc): a lane's
+        // registers are 16-byte pieces of 16 different rows per store instruction; staged, a wave instruction writes one
+        // whole 1 KB row (the projection epilogue's output went from 8-byte pieces to row segments the same way:
+        // 152-173 -> 136-156 us for FFN + in_proj, tools/bench_ffn_proj.py).
+        constexpr int SS = 260;                                   // floats per staged row: 16-byte lane writes of 8 rows hit 32 banks
+        float *stg = reinterpret_cast<float *>(smem);
+        lds_barrier();                                            // every wave is done with the last GEMM's fragments
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                *reinterpret_cast<float4 *>(stg + (th * 64 + nb * 16 + l15) * SS + f0 + mb * 16) =
+                    make_float4(r[nb][mb][0], r[nb][mb][1], r[nb][mb][2], r[nb][mb][3]);
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < TOK * 64 / NT; ++i) {
+            const int idx = tid + NT * i, row = idx >> 6, chunk = idx & 63;
+            const float4 v = *reinterpret_cast<const float4 *>(stg + row * SS + chunk * 4);
+            if (t0 + row < M) *reinterpret_cast<float4 *>(p.x_out + (int64_t)(t0 + row) * D + chunk * 4) = v;
+        }
+    }
+    if constexpr (PROJ) {
+        // ---- projection epilogue.  h = LN2(r) goes to LDS in bf16 (the token tile of the GEMMs above is dead), then
+        // 256-wide output slabs: wave = 64 features x 64 tokens, K = 256, weights through the same ring
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.proj_w), 0, p.proj_dim * D * 2, 0x00020000);
+        auto pload = [&](int ps, int s, bf16x8(&dst)[4]) {       // band (ps*256 + wave*64)/16 + mb, k-tile s
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                dst[mb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rp, vl, (((ps * 256 + wave * 64) / 16 + mb) * (D / 32) + s) * 1024, 0));
+        };
+#pragma unroll
+        for (int s = 0; s < PF; ++s) pload(0, s, wq[s]);          // in flight under the LayerNorm below
+        if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
+        lds_barrier();                                            // (layer_norm's own barriers already order the last GEMM's reads)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                uint2 pk;
+                pk.x = pack2(r[nb][mb][0], r[nb][mb][1]);
+                pk.y = pack2(r[nb][mb][2], r[nb][mb][3]);
+                *reinterpret_cast<uint2 *>(xn + (th * 64 + nb * 16 + l15) * XS + f0 + mb * 16) = pk;
+            }
+        lds_barrier();
+        uint16_t *po = reinterpret_cast<uint16_t *>(p.proj_out);
+        const int nps = p.proj_dim / 256;
+        for (int ps = 0; ps < nps; ++ps) {
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 bfa[4], bfb[4];
+            read_frags(xfrag, 0, bfa);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                bf16x8(&cur)[4] = (s & 1) ? bfb : bfa;
+                bf16x8(&nxt)[4] = (s & 1) ? bfa : bfb;
+                if (s + 1 < 8) read_frags(xfrag, s + 1, nxt);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc[mb][nb], 0, 0, 0);
+                if (s + PF < 8) pload(ps, s + PF, wq[s % PF]);
+                else if (ps + 1 < nps) pload(ps + 1, s + PF - 8, wq[s % PF]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias, bf16, and out through LDS: a lane's accumulators are 4 features of 16 different tokens (8-byte pieces of
+            // 16 rows per store instruction); staged in the free hidden-slab tile they leave as whole 512-byte row segments
+            const int fcol = ps * 256 + f0;
+            if (ps > 0) lds_barrier();                            // the previous slab's rows have been read out
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.proj_b) bv = *reinterpret_cast<const float4 *>(p.proj_b + fcol + mb * 16);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    uint2 pk;
+                    pk.x = pack2(acc[mb][nb][0] + bv.x, acc[mb][nb][1] + bv.y);
+                    pk.y = pack2(acc[mb][nb][2] + bv.z, acc[mb][nb][3] + bv.w);
+                    *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < TOK * 32 / NT; ++i) {
+                const int idx = tid + NT * i, row = idx >> 5, chunk = idx & 31;
+                const uint4 v = *reinterpret_cast<const uint4 *>(hc + row * XS + chunk * 8);
+                if (t0 + row < M) *reinterpret_cast<uint4 *>(po + (int64_t)(t0 + row) * p.proj_dim + ps * 256 + chunk * 8) = v;
+            }
+        }
+        return;
     }
     if (p.h_out) {
         if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
@@ -359,12 +456,12 @@ __global__ void ffn_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__rest
     *reinterpret_cast<uint4 *>(out + piece * 8) = *reinterpret_cast<const uint4 *>(w + (int64_t)r * K + k);
 }
 
-template <bool ADD, int VAR>
+template <bool ADD, int VAR, bool PROJ = false>
 int launch_var(const cm_ffn_args &a) {
     const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)4 * TOK * sizeof(float) + (size_t)a.hidden * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<ADD, VAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<ADD, VAR, PROJ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -373,18 +470,20 @@ int launch_var(const cm_ffn_args &a) {
         attr_done = true;
     }
     dim3 grid((a.rows + TOK - 1) / TOK);
-    hipLaunchKernelGGL((ffn_fused_kernel<ADD, VAR>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    hipLaunchKernelGGL((ffn_fused_kernel<ADD, VAR, PROJ>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_ffn_fused");
 }
 
 template <bool ADD>
 int launch(const cm_ffn_args &a) {
+    if (a.proj_w) return cm_debug_get() == 26 ? launch_var<ADD, 26, true>(a) : launch_var<ADD, 0, true>(a);
     switch (cm_debug_get()) {
         case 1: return launch_var<ADD, 1>(a);
         case 2: return launch_var<ADD, 2>(a);
         case 3: return launch_var<ADD, 3>(a);
         case 4: return launch_var<ADD, 4>(a);
         case 5: return launch_var<ADD, 5>(a);
+        case 26: return launch_var<ADD, 26>(a);
         default: return launch_var<ADD, 0>(a);
     }
 }
@@ -410,7 +509,10 @@ extern "C" int cm_ffn_fused(const cm_ffn_args *args) {
     CM_REQUIRE(a.hidden >= CH && a.hidden % CH == 0 && a.hidden <= 2048, CM_EUNSUPPORTED,
                "ffn_fused: hidden must be a multiple of 256, at most 2048 (got %d)", a.hidden);
     CM_REQUIRE((!a.n1_g || a.n1_b) && (!a.n2_g || a.n2_b), CM_EINVAL, "ffn_fused: LayerNorm weight without bias");
-    CM_REQUIRE(a.x_out || a.h_out, CM_EINVAL, "ffn_fused: neither x_out nor h_out given");
+    CM_REQUIRE(a.x_out || a.h_out || a.proj_w, CM_EINVAL, "ffn_fused: neither x_out nor h_out nor a projection given");
+    CM_REQUIRE(!a.proj_w || (a.proj_out && !a.h_out && a.proj_dim >= 256 && a.proj_dim % 256 == 0 && a.proj_dim <= 4096 &&
+                              cm_aligned(a.proj_w, 16) && cm_aligned(a.proj_out, 16) && (!a.proj_b || cm_aligned(a.proj_b, 16))),
+               CM_EINVAL, "ffn_fused: the projection needs proj_out, no h_out, proj_dim a multiple of 256 (<= 4096), aligned tensors");
     CM_REQUIRE(!a.h_out || a.h_dtype == CM_F32 || a.h_dtype == CM_BF16, CM_EINVAL, "ffn_fused: h_dtype must be f32 or bf16");
     CM_REQUIRE(cm_aligned(a.x, 16) && cm_aligned(a.w1, 16) && cm_aligned(a.w2, 16) && cm_aligned(a.b1, 16) && cm_aligned(a.b2, 16) &&
                    cm_aligned(a.pre_g, 16) && cm_aligned(a.pre_b, 16) && (!a.x_out || cm_aligned(a.x_out, 16)) &&

@@ -43,6 +43,10 @@ class _LayerCache:
         m = layer.mamba
         self.d_inner, self.dt_rank, self.d_state = m.d_inner, m.dt_rank, m.d_state
         self.in_proj = c(m.in_proj.weight)
+        self.in_packed = None                                     # in_proj inside cm_ffn_fused (bf16, d_model 256, no bias)
+        if (USE_FFN_INPROJ and dtype == torch.bfloat16 and self.in_proj.is_cuda and self.in_proj.shape[1] == 256
+                and self.in_proj.shape[0] % 256 == 0 and self.in_proj.shape[0] <= 4096 and m.in_proj.bias is None):
+            self.in_packed = ops.PackedWeight(self.in_proj)
         self.in_bias = None if m.in_proj.bias is None else c(m.in_proj.bias)
         half = 0.5 if m.if_devide_out else 1.0
         self.out_cat = c(torch.cat([m.out_proj.weight, m.out_proj.weight], dim=1) * half)      # (D, 2E)
@@ -137,6 +141,10 @@ def _ffn(x, y_in, p, dtype):
     return torch.addmm(p["b2"], h, p["w2"].t())
 
 
+# BiMamba in_proj inside the first cm_ffn_fused of a layer; CM_FFN_INPROJ=0 = library GEMM after the kernel
+USE_FFN_INPROJ = os.environ.get("CM_FFN_INPROJ", "1") == "1"
+
+
 # the convolution module's closing Linear inside cm_glu_dwconv_ln_gelu; CM_DWCONV_LIN=0 = library GEMM after the kernel
 USE_DWCONV_LIN = os.environ.get("CM_DWCONV_LIN", "1") == "1"
 
@@ -177,13 +185,15 @@ def _scan_dirs(c: _LayerCache, ucat, ycat, batch, seqlen, xdbl=None):
     return dirs
 
 
-def bimamba_fused(c: _LayerCache, h, batch, seqlen):
-    """h: LN'd input (rows, D) in the compute dtype -> mixer output (rows, D) (reference bimamba.py:192-253)."""
+def bimamba_fused(c: _LayerCache, h, batch, seqlen, xz=None):
+    """h: LN'd input (rows, D) in the compute dtype -> mixer output (rows, D) (reference bimamba.py:192-253).
+    ``xz``: in_proj's output when the caller already has it (cm_ffn_fused's projection epilogue)."""
     E, R, N = c.d_inner, c.dt_rank, c.d_state
     rows = batch * seqlen
-    xz = h @ c.in_proj.t()                                               # (rows, 2E): [x | z], channels-last
-    if c.in_bias is not None:
-        xz = xz + c.in_bias
+    if xz is None:
+        xz = h @ c.in_proj.t()                                           # (rows, 2E): [x | z], channels-last
+        if c.in_bias is not None:
+            xz = xz + c.in_bias
     xz3 = xz.view(batch, seqlen, 2 * E)
     ucat = torch.empty((batch, seqlen, 2 * E), dtype=xz.dtype, device=xz.device)
     xdbl = None
@@ -218,8 +228,12 @@ def _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln=None):
     """layer_forward with both feed-forward modules on cm_ffn_fused (bf16, d_model 256)."""
     D = x.shape[-1]
     f1, f2 = c.ffn1, c.ffn2
-    _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)   # x += 0.5 ffn1 ; norm1
-    y = bimamba_fused(c, h, batch, seqlen)
+    if c.in_packed is not None:                                                                                # x += 0.5 ffn1 ; norm1 ; in_proj
+        _, xz = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1, proj_w=c.in_packed)
+        y = bimamba_fused(c, None, batch, seqlen, xz=xz)
+    else:
+        _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)   # x += 0.5 ffn1 ; norm1
+        y = bimamba_fused(c, h, batch, seqlen)
     if USE_LN_PW_GLU and c.pw_packed is not None and y.dtype == torch.bfloat16 and y.is_contiguous():
         # x += mamba ; conv-module LN ; pointwise conv ; GLU -- one kernel, the 2D-wide tensor never exists
         gl = ops.ln_pw_glu(x, y, 1.0, c.cm_ln, c.pw_packed, c.pw_bf)
@@ -372,8 +386,12 @@ def _encoder_forward_joined(encoder, src, dtype, ns):
             for pi, (b0, b1) in enumerate(parts):
                 with torch.cuda.stream(streams[pi]):
                     xp = x[b0 * seqlen:b1 * seqlen]
-                    _, h = ops.ffn_fused(xp, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)
-                    torch.mm(h, c.in_proj.t(), out=xz[b0:b1].view(-1, 2 * E))
+                    if c.in_packed is not None:
+                        ops.ffn_fused(xp, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1,
+                                      proj_w=c.in_packed, proj_out=xz[b0:b1].view(-1, 2 * E))
+                    else:
+                        _, h = ops.ffn_fused(xp, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)
+                        torch.mm(h, c.in_proj.t(), out=xz[b0:b1].view(-1, 2 * E))
                     ops.conv_xproj(xz[b0:b1, :, :E], c.dirs[0]["conv_w"], c.dirs[0]["conv_b"], c.dirs[1]["conv_w"], c.dirs[1]["conv_b"],
                                    c.wx_packed[0], c.wx_packed[1], out_f=ucat[b0:b1, :, :E], out_b=ucat[b0:b1, :, E:], xdbl=xdbl[b0:b1])
             join()

@@ -907,13 +907,15 @@ class PackedWeight:
 
 
 def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0, norm1=None, norm2=None,
-              x_out=None, want_h=True, h_dtype=torch.bfloat16):
+              x_out=None, want_h=True, h_dtype=torch.bfloat16, proj_w=None, proj_b=None, proj_out=None):
     """Whole feed-forward module on the fp32 residual stream (cm_ffn_fused):
         xin = x + add_scale*addend;  r = xin + alpha*(W2 gelu(W1 LN_pre(xin) + b1) + b2);  r = LN1(r) if norm1;
         x_out <- r (x itself when x_out is None);  returns h = LN2(r) (or r when norm2 is None) in h_dtype if want_h.
     x (rows, 256) fp32; w1 (hidden, 256) / w2 (256, hidden) bf16 tensors or PackedWeight (pack once, reuse); b1/b2 and
-    LayerNorm parameters fp32; addend (rows, 256) bf16; norm = (weight, bias, eps)."""
-    _dev_check(x, b1, b2, addend)
+    LayerNorm parameters fp32; addend (rows, 256) bf16; norm = (weight, bias, eps).
+    With ``proj_w`` (PackedWeight (P, 256), P % 256 == 0; ``proj_b`` fp32 (P) or None) the Linear that consumes h runs in the
+    same kernel and (rows, P) bf16 = h @ proj_w^T (+ proj_b) is returned in h's place; h itself is not stored."""
+    _dev_check(x, b1, b2, addend, proj_b)
     rows, d = x.shape
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise RuntimeError("ffn_fused: x must be a contiguous fp32 (rows, 256) tensor")
@@ -941,7 +943,16 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
     xo = x if x_out is None else x_out
     a.x_out = _ptr(xo)
     h = None
-    if want_h:
+    if proj_w is not None:
+        if not isinstance(proj_w, PackedWeight) or proj_w.shape[1] != d or proj_w.shape[0] % 256 or proj_w.shape[0] > 4096:
+            raise RuntimeError("ffn_fused: proj_w must be a PackedWeight of shape (P, 256), P a multiple of 256 up to 4096")
+        h = proj_out if proj_out is not None else torch.empty((rows, proj_w.shape[0]), dtype=torch.bfloat16, device=x.device)
+        if h.shape != (rows, proj_w.shape[0]) or h.dtype != torch.bfloat16 or not h.is_contiguous():
+            raise RuntimeError("ffn_fused: proj_out must be a contiguous bf16 (rows, P) tensor")
+        _dev_check(h)
+        pb = _f32c(proj_b)
+        a.proj_w, a.proj_b, a.proj_out, a.proj_dim = _ptr(proj_w.data), _ptr(pb), _ptr(h), proj_w.shape[0]
+    elif want_h:
         h = torch.empty((rows, d), dtype=h_dtype, device=x.device)
         a.h_out, a.h_dtype = _ptr(h), _DT[h_dtype]
     a.stream = _stream()

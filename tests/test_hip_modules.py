@@ -241,6 +241,30 @@ def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt):
         torch.testing.assert_close(h.float().cpu(), want_h, **tol)
 
 
+@pytest.mark.parametrize("rows,pdim,bias", [(64, 1024, False), (1000, 1024, True), (37, 256, False), (200, 2048, True)])
+def test_ffn_fused_projection_epilogue(rows, pdim, bias):
+    """cm_ffn_fused with proj_w: the Linear that consumes h (the BiMamba in_proj, reference bimamba.py:192-200) inside the
+    kernel == the kernel's own bf16 h through an fp32 matmul with the same bf16 weight; the stream output is unchanged."""
+    from mamba_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + pdim)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    x = rn(rows, 256, scale=2.0) + 0.5
+    w1, b1 = rn(1024, 256, scale=256 ** -0.5).bfloat16(), rn(1024, scale=0.1)
+    w2, b2 = rn(256, 1024, scale=1024 ** -0.5).bfloat16(), rn(256, scale=0.1)
+    ln = lambda: (1.0 + 0.1 * rn(256), 0.1 * rn(256), 1e-5)
+    pre, n2 = ln(), ln()
+    wp, bp = rn(pdim, 256, scale=1 / 16).bfloat16(), (rn(pdim, scale=0.1) if bias else None)
+    xa, xb = x.clone(), x.clone()
+    _, h = ops.ffn_fused(xa, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2)
+    _, xz = ops.ffn_fused(xb, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp), proj_b=bp)
+    assert torch.equal(xa, xb) and xz.shape == (rows, pdim) and xz.dtype == torch.bfloat16
+    want = h.float() @ wp.float().t() + (bp if bias else 0.0)
+    torch.testing.assert_close(xz.float(), want, rtol=8e-3, atol=8e-3)
+    out = torch.empty(rows, pdim, dtype=torch.bfloat16, device=DEV)
+    _, xz2 = ops.ffn_fused(x.clone(), pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp), proj_b=bp, proj_out=out)
+    assert xz2.data_ptr() == out.data_ptr() and torch.equal(out, xz)
+
+
 @pytest.mark.parametrize("batch,seqlen", [(2, 100), (3, 37), (1, 1000)])
 def test_ln_pw_glu_kernel_and_pregated_dwconv(batch, seqlen):
     """cm_ln_pw_glu (residual add + LayerNorm + pointwise conv + GLU) vs torch fp32 on the same bf16-rounded operands,
