@@ -486,17 +486,24 @@ __global__ __launch_bounds__(256, DV == 4 ? 4 : 2) void dwconv_rows_kernel(const
             if (ks + PF < D / 32) wload(ks + PF, wq[ks % PF]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // out through LDS (the activation tile is dead once every wave has its fragments): whole 512-byte rows per wave
+        // instruction instead of 8-byte pieces of 16 rows
         const int f0 = wave * 64 + lq * 4;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 bv = *reinterpret_cast<const float4 *>(p.lin_b + f0 + mb * 16);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int t = t0 + nb * 16 + l15;
-                if (t < T)
-                    *reinterpret_cast<uint2 *>(out + (int64_t)t * D + f0 + mb * 16) =
-                        make_uint2(cm_pack_bf16(acc[mb][nb][0] + bv.x, acc[mb][nb][1] + bv.y), cm_pack_bf16(acc[mb][nb][2] + bv.z, acc[mb][nb][3] + bv.w));
-            }
+            for (int nb = 0; nb < 2; ++nb)
+                *reinterpret_cast<uint2 *>(xt + (nb * 16 + l15) * XS + f0 + mb * 16) =
+                    make_uint2(cm_pack_bf16(acc[mb][nb][0] + bv.x, acc[mb][nb][1] + bv.y), cm_pack_bf16(acc[mb][nb][2] + bv.z, acc[mb][nb][3] + bv.w));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TT * 32 / 256; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 5, chunk = idx & 31;
+            const uint4 v = *reinterpret_cast<const uint4 *>(xt + row * XS + chunk * 8);
+            if (t0 + row < T) *reinterpret_cast<uint4 *>(out + (int64_t)(t0 + row) * D + chunk * 8) = v;
         }
     }
 }
@@ -702,7 +709,7 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
     CM_REQUIRE(a.ksize == 31, CM_EUNSUPPORTED, "glu_dwconv: kernel size %d unsupported (31 only)", a.ksize);
     CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
     hipStream_t st0 = reinterpret_cast<hipStream_t>(a.stream);
-    if (a.io_dtype == CM_BF16 && (a.dim == 256 || a.dim == 512) && cm_debug_get() != 31 && cm_aligned(a.in, 16) && cm_aligned(a.out, 8) &&
+    if (a.io_dtype == CM_BF16 && (a.dim == 256 || a.dim == 512) && cm_debug_get() != 31 && cm_aligned(a.in, 16) && cm_aligned(a.out, 16) &&
         (!a.weight_t || cm_aligned(a.weight_t, 8)) && (!a.bias || cm_aligned(a.bias, 8)) && cm_aligned(a.ln_g, 16) && cm_aligned(a.ln_b, 16)) {
         constexpr int TT = 32;
         const dim3 grid((a.seqlen + TT - 1) / TT, a.batch);
