@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256, OCC) void ln_pw_glu_kernel(const cm_ln_pw_glu_
         for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const bf16x8 *>(xfrag + nb * 16 * XS + ks * 32);
     };
     uint16_t *out = reinterpret_cast<uint16_t *>(p.out);
+    // The gated outputs leave through LDS: a lane's accumulators are 4 features of 16 different tokens (8-byte pieces of 16 rows
+    // per store instruction); the first pass's results wait in registers (the token tile is still being read), then both
+    // passes are laid into the dead tile and stored as whole 512-byte rows.
+    uint2 held[2][4];
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         f32x4 acc[2][2][4];
@@ -150,14 +154,25 @@ __global__ __launch_bounds__(256, OCC) void ln_pw_glu_kernel(const cm_ln_pw_glu_
             const float4 bg = *reinterpret_cast<const float4 *>(p.bias + D + f0 + mb * 16);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const int tok = t0 + nb * 16 + l15;
                 const float o0 = (acc[0][mb][nb][0] + ba.x) * cm_sigmoid(acc[1][mb][nb][0] + bg.x);
                 const float o1 = (acc[0][mb][nb][1] + ba.y) * cm_sigmoid(acc[1][mb][nb][1] + bg.y);
                 const float o2 = (acc[0][mb][nb][2] + ba.z) * cm_sigmoid(acc[1][mb][nb][2] + bg.z);
                 const float o3 = (acc[0][mb][nb][3] + ba.w) * cm_sigmoid(acc[1][mb][nb][3] + bg.w);
-                if (tok < M) *reinterpret_cast<uint2 *>(out + (int64_t)tok * D + f0 + mb * 16) = uint2{pack2(o0, o1), pack2(o2, o3)};
+                if (ps == 0) held[mb][nb] = uint2{pack2(o0, o1), pack2(o2, o3)};
+                else {
+                    if (mb == 0 && nb == 0) lds_barrier();        // every wave has read its last token fragments
+                    *reinterpret_cast<uint2 *>(xn + (nb * 16 + l15) * XS + f0 + mb * 16) = uint2{pack2(o0, o1), pack2(o2, o3)};
+                    *reinterpret_cast<uint2 *>(xn + (nb * 16 + l15) * XS + f0 - 32 + mb * 16) = held[mb][nb];
+                }
             }
         }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < TOK * 32 / 256; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 5, chunk = idx & 31;
+        const uint4 v = *reinterpret_cast<const uint4 *>(xn + row * XS + chunk * 8);
+        if (t0 + row < M) *reinterpret_cast<uint4 *>(out + (int64_t)(t0 + row) * D + chunk * 8) = v;
     }
 }
 
@@ -169,7 +184,7 @@ extern "C" int cm_ln_pw_glu(const cm_ln_pw_glu_args *args) {
     CM_REQUIRE(a.rows > 0 && a.x && a.ln_g && a.ln_b && a.w && a.bias && a.out, CM_EINVAL, "ln_pw_glu: bad sizes or NULL tensor");
     CM_REQUIRE(a.dim == D, CM_EUNSUPPORTED, "ln_pw_glu: d_model must be 256 (got %d)", a.dim);
     CM_REQUIRE(cm_aligned(a.x, 16) && cm_aligned(a.ln_g, 16) && cm_aligned(a.ln_b, 16) && cm_aligned(a.w, 16) && cm_aligned(a.bias, 16) &&
-                   cm_aligned(a.out, 8) && (!a.y || cm_aligned(a.y, 8)) && (!a.x_out || cm_aligned(a.x_out, 16)),
+                   cm_aligned(a.out, 16) && (!a.y || cm_aligned(a.y, 8)) && (!a.x_out || cm_aligned(a.x_out, 16)),
                CM_EALIGN, "ln_pw_glu: tensors must be 16-byte aligned (y / out 8)");
     const dim3 grid((a.rows + TOK - 1) / TOK);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
