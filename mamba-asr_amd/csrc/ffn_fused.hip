@@ -236,14 +236,41 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     // front of its weight fragments in the in-order return queue: in-kernel stamps showed that GEMM taking 10.8 k ticks
     // against 3-4 k for the others (profiles/r02/ffn_stamps_and_variants.log); 120 / 108 / 105 -> 110 / 103 / 100 us for the
     // second FFN of a layer, 12.52 -> 12.44 ms per step.
+    // They come in as whole rows (a wave instruction = one 1 KB row, + its bf16 addend row) and reach the accumulator layout
+    // through LDS -- read straight into that layout they are 16-byte pieces of 16 rows per instruction, on the critical path.
+    if constexpr (VAR == 25) {                                    // timing variant: the direct reads
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int tok = min(t0 + th * 64 + nb * 16 + l15, M - 1);
+        for (int nb = 0; nb < 4; ++nb) {
+            const int tok = min(t0 + th * 64 + nb * 16 + l15, M - 1);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const float4 xv = load_x4(tok, f0 + mb * 16);
-            r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 xv = load_x4(tok, f0 + mb * 16);
+                r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
+            }
         }
+    } else {
+        constexpr int SR = 260;
+        float *stg = reinterpret_cast<float *>(smem);
+        float4 rows_[TOK * 64 / NT];
+#pragma unroll
+        for (int i = 0; i < TOK * 64 / NT; ++i) {
+            const int idx = tid + NT * i;
+            rows_[i] = load_x4(min(t0 + (idx >> 6), M - 1), (idx & 63) * 4);
+        }
+        lds_barrier();                                            // every wave is done with the last GEMM's fragments
+#pragma unroll
+        for (int i = 0; i < TOK * 64 / NT; ++i) {
+            const int idx = tid + NT * i;
+            *reinterpret_cast<float4 *>(stg + (idx >> 6) * SR + (idx & 63) * 4) = rows_[i];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 xv = *reinterpret_cast<const float4 *>(stg + (th * 64 + nb * 16 + l15) * SR + f0 + mb * 16);
+                r[nb][mb][0] = xv.x; r[nb][mb][1] = xv.y; r[nb][mb][2] = xv.z; r[nb][mb][3] = xv.w;
+            }
     }
 
     // ---- epilogue: r = xin + alpha (acc2 + b2); optional LN1 -> stream; optional LN2 -> h_out.
@@ -476,13 +503,14 @@ int launch_var(const cm_ffn_args &a) {
 
 template <bool ADD>
 int launch(const cm_ffn_args &a) {
-    if (a.proj_w) return cm_debug_get() == 26 ? launch_var<ADD, 26, true>(a) : launch_var<ADD, 0, true>(a);
+    if (a.proj_w) return cm_debug_get() == 26 ? launch_var<ADD, 26, true>(a) : (cm_debug_get() == 25 ? launch_var<ADD, 25, true>(a) : launch_var<ADD, 0, true>(a));
     switch (cm_debug_get()) {
         case 1: return launch_var<ADD, 1>(a);
         case 2: return launch_var<ADD, 2>(a);
         case 3: return launch_var<ADD, 3>(a);
         case 4: return launch_var<ADD, 4>(a);
         case 5: return launch_var<ADD, 5>(a);
+        case 25: return launch_var<ADD, 25>(a);
         case 26: return launch_var<ADD, 26>(a);
         default: return launch_var<ADD, 0>(a);
     }
