@@ -1,4 +1,5 @@
-"""cm_ffn_fused at 64k rows: kernel variants selected with cm_debug_set (0 = four waves x 64 features, 28 = eight waves x 32)."""
+"""cm_ffn_fused at 64k rows: kernel variants selected with cm_debug_set (0 = the kernel as shipped, 25 = residual rows read
+straight into the accumulator layout, 26 = stream rows stored from it; 1-5 the round-1 ablations)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,7 @@ b1, b2 = torch.randn(F, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1
 lib = _native.lib()
 ffn2 = lambda: ops.ffn_fused(x, n1, w1, b1, w2, b2, alpha=0.5, addend=add, norm1=n1, want_h=False)      # second FFN of a layer
 ffn1 = lambda: ops.ffn_fused(x, n1, w1, b1, w2, b2, alpha=0.5, norm2=n1)                                 # first FFN (h out)
-for variant in [int(v) for v in os.environ.get("VARIANTS", "0,28,0,28").split(",")]:
+for variant in [int(v) for v in os.environ.get("VARIANTS", "0,25,26,0,25,26").split(",")]:
     lib.cm_debug_set(variant)
     out = []
     for fn in (ffn1, ffn2):
