@@ -104,6 +104,10 @@ class ConmambaEncoderLayer(nn.Module):
         self.ffn_module2 = ffn()
         self.norm1 = LayerNorm(d_model)
         self.norm2 = LayerNorm(d_model)
+        # these four norms feed a projection and nothing else (feed-forward Linear, BiMamba in_proj, pointwise conv): under
+        # autocast their kernel stores the projection's operand dtype itself (sb_compat.RowsLayerNorm.low_out)
+        for ln in (self.ffn_module1[0], self.ffn_module2[0], self.norm1.norm, self.convolution_module.layer_norm):
+            ln.low_out = True
         self.drop = nn.Dropout(dropout)
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None):

@@ -714,8 +714,10 @@ class LayerNormFn(torch.autograd.Function):
     input dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, low_dtype=None):
         out_dtype = torch.float32 if (x.dtype == torch.float32 or torch.is_autocast_enabled("cuda")) else x.dtype
+        if low_dtype is not None:                             # the consumer is a projection that would round to low_dtype anyway
+            out_dtype = low_dtype
         y, x2, stats = layernorm_fwd(x, weight, bias, eps, out_dtype)
         ctx.save_for_backward(x2, stats, weight)
         ctx.eps, ctx.shape = eps, x.shape
@@ -727,7 +729,7 @@ class LayerNormFn(torch.autograd.Function):
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
         dx, dg, db = layernorm_bwd(dy, x2, stats, weight, ctx.eps, need_dx=ctx.needs_input_grad[0])
-        return (dx.view(ctx.shape) if dx is not None else None), dg.to(weight.dtype), db.to(weight.dtype), None
+        return (dx.view(ctx.shape) if dx is not None else None), dg.to(weight.dtype), db.to(weight.dtype), None, None
 
 
 def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):

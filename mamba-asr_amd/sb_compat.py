@@ -30,9 +30,21 @@ class Swish(nn.Module):
 USE_NATIVE_LN = os.environ.get("CM_NATIVE_LN", "1") == "1"
 
 
+# CM_LN_LOW_OUT=0: LayerNorms in front of a projection return fp32 under autocast (torch's behaviour) instead of the
+# projection's operand dtype
+LN_LOW_OUT = os.environ.get("CM_LN_LOW_OUT", "1") == "1"
+
+
 class RowsLayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters and state_dict keys) whose GPU forward/backward run on the native kernels (rows of up
-    to 4096 normalised elements, contiguous); anything else and CPU tensors take torch's path."""
+    to 4096 normalised elements, contiguous); anything else and CPU tensors take torch's path.
+
+    ``low_out``: set by a parent module whose ONLY consumer of this norm's output is a Linear / projection.  Under autocast
+    torch returns fp32 from layer_norm and the Linear then rounds it to the autocast dtype with a cast kernel (and a cast
+    back in backward); with ``low_out`` the native kernel stores that same rounding itself (round to nearest even of the
+    same fp32 value: bit-identical operands for the GEMM), and the backward kernel takes the low-precision gradient."""
+
+    low_out = False
 
     def forward(self, x):
         dim = math.prod(self.normalized_shape)
@@ -41,7 +53,8 @@ class RowsLayerNorm(nn.LayerNorm):
                 and (len(self.normalized_shape) == 1 or x.is_contiguous())):
             from . import ops
             if len(self.normalized_shape) == 1:
-                return ops.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+                low = (torch.get_autocast_dtype("cuda") if (self.low_out and LN_LOW_OUT and torch.is_autocast_enabled("cuda")) else None)
+                return ops.LayerNormFn.apply(x, self.weight, self.bias, self.eps, low)
             # several trailing axes (the CNN front end's (frequency, channel) norm): rows of their product
             lead = x.shape[:x.dim() - len(self.normalized_shape)]
             y = ops.LayerNormFn.apply(x.reshape(*lead, dim), self.weight.reshape(dim), self.bias.reshape(dim), self.eps)

@@ -400,6 +400,30 @@ def test_cnn_block2_kernel(batch, t_in, f_in):
     assert (got.float().cpu() - ref).abs().mean() < 2e-3
 
 
+def test_layernorm_low_out_is_bit_identical_under_autocast(monkeypatch):
+    """The encoder layer's projection-feeding LayerNorms store the autocast dtype themselves (RowsLayerNorm.low_out): the
+    GEMMs see the same bf16 operands as with torch's fp32 LayerNorm output + cast, so the layer's forward output and its
+    gradients are bit-identical with the switch off."""
+    from mamba_asr_amd import sb_compat
+    from mamba_asr_amd.modules.Conmamba import ConmambaEncoderLayer
+    torch.manual_seed(9)
+    layer = ConmambaEncoderLayer(d_model=256, d_ffn=512, kernel_size=31, activation=nn.GELU, bias=True, dropout=0.0,
+                                 causal=False, mamba_config=dict(CFG)).to(DEV).train()
+    assert layer.norm1.norm.low_out and layer.ffn_module1[0].low_out and not layer.norm2.norm.low_out
+    x0 = torch.randn(2, 50, 256, device=DEV)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(sb_compat, "LN_LOW_OUT", flag)
+        x = x0.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = layer(x)
+        y.float().square().mean().backward()
+        res.append((y.detach().clone(), x.grad.clone(), layer.ffn_module1[0].weight.grad.clone(), layer.norm1.norm.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_ffn_fused_rejects_unsupported():
     from mamba_asr_amd import ops
     x = torch.zeros(8, 128, device=DEV)
