@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 5
+#define CM_ABI_VERSION 6
 
 /* error codes */
 #define CM_OK            0
@@ -52,15 +52,14 @@ int         cm_abi_version(void);
 const char *cm_last_error(void);
 /* number of checkpoint chunks for a sequence length: ceil(seqlen / CM_SCAN_CHUNK) */
 int         cm_scan_num_chunks(int seqlen);
-/* Tuning override for the scan kernels' lane split (lanes per channel): 1, 2, 4, 8 or 16;
- * 0 restores the automatic choice (also settable with the CM_SCAN_SPLIT environment variable).
- * Returns the previous value.  Process-wide; meant for tests and benchmarks. */
-int         cm_scan_set_split(int lanes_per_channel);
-/* Timing-only ablation switch of the scan kernels (0 = product kernel; 1..5 select builds with one stage removed, see
- * csrc/scan_rows_fwd.hip / scan_cl_fwd.hip; results are then WRONG by construction).  Returns the previous value.
- * Process-wide; used by tools/bench_scan.py to produce the ablation table in DESIGN.md. */
+#ifdef CM_ABLATE
+/* Ablation build only (make -C mamba_asr_amd/csrc ablate -> lib/libconmamba_hip_ablate.so, loaded by the tools through
+ * CM_LIB_PATH): a process-wide switch selecting timing-only kernel variants with one stage removed (results are then WRONG by
+ * construction; tools/bench_scan.py, bench_ffn.py produce DESIGN.md's ablation tables with it).  The product library is
+ * compiled without CM_ABLATE: it has no such switch, no ablation kernels and no process-global mutable state. */
 int         cm_debug_set(int ablation);
 int         cm_debug_get(void);
+#endif
 
 /* ---------------------------------------------------------------------------------------
  * Selective scan forward — replaces selective_scan_cuda.fwd
@@ -111,6 +110,10 @@ typedef struct cm_scan_fwd_args {
                                 time-split scan across GPUs exchanges (no
                                 reference counterpart: the reference has no sequence parallelism,
                                 SURVEY.md §5)                                               */
+    int32_t lanes_per_channel; /* tuning: lanes one channel's states are split over (1, 2, 4, 8, 16; backward: 4, 8,
+                                16); 0 = the library's choice from the problem size.  Results do not depend on it
+                                beyond fp32 summation order                                  */
+    int32_t pad4_;
 } cm_scan_fwd_args;
 
 int cm_selective_scan_fwd(const cm_scan_fwd_args *args);
@@ -248,6 +251,8 @@ typedef struct cm_scan_cl_args {
     void *stream;
     void   *workspace;       /* time_chunks > 1: cm_scan_cl_fwd_workspace_bytes(args) bytes, 16-byte aligned, caller owned */
     int64_t workspace_bytes;
+    int32_t lanes_per_channel; /* tuning, state-split kernel (no xdbl) only: 4, 8 or 16 lanes per channel; 0 = automatic */
+    int32_t pad5_;
 } cm_scan_cl_args;
 
 int cm_scan_cl_fwd(const cm_scan_cl_args *args);
@@ -297,7 +302,8 @@ typedef struct cm_conv_xproj_args {
     int32_t dt_pad;                                       /* 0 / 16: x_dbl rows [dt16 | B | C] per direction (96 columns in all);
                                                              32: [dt32 | B | C] (128 columns), the layout cm_scan_cl_fwd's xdbl
                                                              mode takes for 16 < dt_rank <= 32                                   */
-    int32_t pad_;
+    int32_t variant;                                      /* tuning: 0 = tile shape chosen from the problem size; 1 = always the
+                                                             16-step tiles (the shape small launches get)                        */
 } cm_conv_xproj_args;
 
 int cm_conv_xproj(const cm_conv_xproj_args *args);
@@ -346,7 +352,7 @@ typedef struct cm_glu_dwconv_args {
     const float *bias;           /* (dim) or NULL                                      */
     const float *ln_g, *ln_b;    /* (dim)                                              */
     float eps;
-    int32_t pad2_;
+    int32_t variant;             /* tuning: 0 = kernel chosen from dtype / dim; 1 = always the generic 16-step kernel  */
     void *out;                   /* (batch, seqlen, dim), contiguous                   */
     void *stream;
     const float *weight_t;       /* optional (ksize, dim) copy of the taps: per-channel reads become coalesced */

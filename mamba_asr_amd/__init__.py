@@ -1,9 +1,11 @@
-# Import alias: the product package lives in the directory "mamba-asr_amd/", whose name is not a
-# valid Python identifier.  This stub makes `import mamba_asr_amd` resolve to it.
-import os as _os
+"""mamba_asr_amd — MI355X-native ConMamba ASR encoder hot path.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mamba-asr_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+Python host code (this package) calls through a C ABI (include/conmamba_hip.h,
+mamba_asr_amd/lib/libconmamba_hip.so) into hand-written HIP kernels for gfx950.
+Importing the package does not load the library; the first op does, and raises if it is missing.
+
+"""
+__version__ = "0.1.0"
+
+from . import _native  # noqa: F401
+from . import ops  # noqa: F401

@@ -1,7 +1,7 @@
 """ctypes binding of libconmamba_hip.so (C ABI: include/conmamba_hip.h).
 
-The library is built in-tree (``mamba-asr_amd/lib/libconmamba_hip.so``) by
-``__graft_entry__.build()`` / ``make -C mamba-asr_amd/csrc``.  There is no CPU fallback:
+The library is built in-tree (``mamba_asr_amd/lib/libconmamba_hip.so``) by
+``__graft_entry__.build()`` / ``make -C mamba_asr_amd/csrc``.  There is no CPU fallback:
 if the library is missing or a call fails, a RuntimeError is raised.
 """
 from __future__ import annotations
@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -27,7 +27,7 @@ class ScanFwdArgs(C.Structure):
         ("out", vp), ("out_z", vp), ("x", fp),
         ("u_bs", i64), ("u_ds", i64), ("delta_bs", i64), ("delta_ds", i64), ("z_bs", i64), ("z_ds", i64),
         ("out_bs", i64), ("out_ds", i64), ("B_bs", i64), ("B_ns", i64), ("C_bs", i64), ("C_ns", i64),
-        ("stream", vp), ("h0", fp),
+        ("stream", vp), ("h0", fp), ("lanes_per_channel", i32), ("pad4_", i32),
     ]
 
 
@@ -72,7 +72,7 @@ class ScanClArgs(C.Structure):
         ("z", vp), ("z_bs", i64), ("z_ts", i64),
         ("dir", ScanClDir * 2),
         ("stream", vp),
-        ("workspace", vp), ("workspace_bytes", i64),
+        ("workspace", vp), ("workspace_bytes", i64), ("lanes_per_channel", i32), ("pad5_", i32),
     ]
 
 
@@ -91,7 +91,7 @@ class ConvXprojArgs(C.Structure):
         ("x", vp), ("weight_f", fp), ("bias_f", fp), ("weight_b", fp), ("bias_b", fp), ("wx_f", vp), ("wx_b", vp),
         ("y_fwd", vp), ("y_bwd", vp), ("xdbl", vp),
         ("x_bs", i64), ("x_ts", i64), ("yf_bs", i64), ("yf_ts", i64), ("yb_bs", i64), ("yb_ts", i64),
-        ("xdbl_bs", i64), ("xdbl_ts", i64), ("stream", vp), ("dt_pad", i32), ("pad_", i32),
+        ("xdbl_bs", i64), ("xdbl_ts", i64), ("stream", vp), ("dt_pad", i32), ("variant", i32),
     ]
 
 
@@ -162,7 +162,7 @@ class AddLnArgs(C.Structure):
 class GluDwconvArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("ksize", i32), ("io_dtype", i32), ("glu_done", i32),
-        ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("pad2_", i32),
+        ("in_", vp), ("weight", fp), ("bias", fp), ("ln_g", fp), ("ln_b", fp), ("eps", C.c_float), ("variant", i32),
         ("out", vp), ("stream", vp), ("weight_t", fp), ("lin_w", vp), ("lin_b", fp),
     ]
 
@@ -224,14 +224,11 @@ SYMBOLS = [
     ("cm_abi_version", C.c_int, []),
     ("cm_last_error", C.c_char_p, []),
     ("cm_scan_num_chunks", C.c_int, [C.c_int]),
-    ("cm_scan_set_split", C.c_int, [C.c_int]),
     ("cm_selective_scan_fwd", C.c_int, [C.POINTER(ScanFwdArgs)]),
     ("cm_selective_scan_bwd", C.c_int, [C.POINTER(ScanBwdArgs)]),
     ("cm_selective_scan_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanBwdArgs)]),
     ("cm_causal_conv1d_fwd", C.c_int, [C.POINTER(ConvArgs)]),
     ("cm_causal_conv1d_bwd", C.c_int, [C.POINTER(ConvArgs)]),
-    ("cm_debug_set", C.c_int, [C.c_int]),
-    ("cm_debug_get", C.c_int, []),
     ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
     ("cm_scan_cl_fwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClArgs)]),
     ("cm_scan_cl_fwd_auto_chunks", i32, [i32, i32, i32, i32]),
@@ -272,7 +269,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C mamba-asr_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+                "or `make -C mamba_asr_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
         handle = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(handle, name)      # AttributeError if the .so lacks a declared symbol
@@ -280,8 +277,11 @@ def lib():
         got = handle.cm_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError(f"libconmamba_hip ABI {got} != binding {ABI_VERSION}: rebuild the library")
-        if os.environ.get("CM_DEBUG"):      # timing-only kernel variants (cm_debug_set), for A/B runs of whole programs
-            handle.cm_debug_set(int(os.environ["CM_DEBUG"]))
+        if hasattr(handle, "cm_debug_set"):  # the ablation build (make ablate; CM_LIB_PATH): timing-only kernel variants
+            handle.cm_debug_set.restype, handle.cm_debug_set.argtypes = C.c_int, [C.c_int]
+            handle.cm_debug_get.restype, handle.cm_debug_get.argtypes = C.c_int, []
+            if os.environ.get("CM_DEBUG"):
+                handle.cm_debug_set(int(os.environ["CM_DEBUG"]))
         _lib = handle
     return _lib
 

@@ -30,6 +30,14 @@ static inline int cm_launch_status(const char *what) {
     return CM_OK;
 }
 
+// Ablation switch: exists in the ablation build only (-DCM_ABLATE, `make ablate`); the product library sees a constant 0, so
+// every `cm_debug_get() == k` branch and the kernel variants behind it compile away and no process-global state is left.
+#ifdef CM_ABLATE
+extern "C" int cm_debug_get();
+#else
+static constexpr int cm_debug_get() { return 0; }
+#endif
+
 static inline bool cm_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ---------------------------------------------------------------------------------------

@@ -14,7 +14,6 @@
 // HBM traffic: x once (+ a 6-row halo per 16, served by the XCD's L2), u twice E per step written, 192 B of x_dbl per step.
 #include "cm_common.h"
 
-extern "C" int cm_debug_get();
 
 namespace {
 
@@ -47,7 +46,12 @@ __device__ __forceinline__ unsigned long long cx_now() {
 
 // NB: 16-column bands of x_dbl per direction: 3 = [dt16 | B | C], 4 = [dt32 | B | C] (dt_rank 17..32: the S2S-large encoder)
 template <int TT, int NB>
-__global__ __launch_bounds__(256, (TT == 16 && NB == 3) ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile, const int stamp = 0) {
+__global__ __launch_bounds__(256, (TT == 16 && NB == 3) ? 4 : 2) void conv_xproj_kernel(const cm_conv_xproj_args p, const int ntile, const int stamp_arg = 0) {
+#ifdef CM_ABLATE
+    const int stamp = stamp_arg;
+#else
+    constexpr int stamp = 0;                                          // product build: no stamps, no A / B variant
+#endif
     const bool st_wg = stamp == 1 && blockIdx.x == gridDim.x / 2 + 3;
     unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
     if (st_wg) ts_[0] = cx_now();
@@ -269,9 +273,11 @@ int launch_cx(const cm_conv_xproj_args &a) {
 
 }  // namespace
 
+#ifdef CM_ABLATE
 extern "C" int cm_debug_read_stamps_cx(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cx_stamps), sizeof(unsigned long long) * 16);
 }
+#endif
 
 extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "conv_xproj: args is NULL");
@@ -286,7 +292,7 @@ extern "C" int cm_conv_xproj(const cm_conv_xproj_args *args) {
                    a.yb_ts % 4 == 0 && a.xdbl_bs % 4 == 0 && a.xdbl_ts % 4 == 0,
                CM_EALIGN, "conv_xproj: tensors must be 8-byte aligned (weights 16) with strides that are multiples of 4 elements");
     // 32-step tiles when the LDS tiles fit twice per CU and the sequence is long enough to fill the chip with them
-    const bool wide = cm_debug_get() != 16 && (size_t)2 * 32 * (a.dim + 16) * 2 <= 72 * 1024 && (long)a.batch * ((a.seqlen + 31) / 32) >= 512;
+    const bool wide = a.variant != 1 && (size_t)2 * 32 * (a.dim + 16) * 2 <= 72 * 1024 && (long)a.batch * ((a.seqlen + 31) / 32) >= 512;
     CM_REQUIRE(a.dt_pad == 0 || a.dt_pad == 16 || a.dt_pad == 32, CM_EUNSUPPORTED, "conv_xproj: dt_pad %d (16 or 32)", a.dt_pad);
     if (a.dt_pad == 32) {
         CM_REQUIRE((size_t)2 * 16 * (a.dim + 16) * 2 <= 80 * 1024, CM_EUNSUPPORTED, "conv_xproj: dim %d too wide for 64-column rows", a.dim);

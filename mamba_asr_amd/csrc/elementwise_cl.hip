@@ -5,7 +5,6 @@
 // All are HBM-bound: 16-byte vectors along the contiguous channel axis, every input read once.
 #include "cm_common.h"
 
-extern "C" int cm_debug_get();
 
 namespace {
 
@@ -709,7 +708,7 @@ extern "C" int cm_glu_dwconv_ln_gelu(const cm_glu_dwconv_args *args) {
     CM_REQUIRE(a.ksize == 31, CM_EUNSUPPORTED, "glu_dwconv: kernel size %d unsupported (31 only)", a.ksize);
     CM_REQUIRE(a.dim % 2 == 0, CM_EUNSUPPORTED, "glu_dwconv: dim must be even");
     hipStream_t st0 = reinterpret_cast<hipStream_t>(a.stream);
-    if (a.io_dtype == CM_BF16 && (a.dim == 256 || a.dim == 512) && cm_debug_get() != 31 && cm_aligned(a.in, 16) && cm_aligned(a.out, 16) &&
+    if (a.io_dtype == CM_BF16 && (a.dim == 256 || a.dim == 512) && a.variant != 1 && cm_aligned(a.in, 16) && cm_aligned(a.out, 16) &&
         (!a.weight_t || cm_aligned(a.weight_t, 8)) && (!a.bias || cm_aligned(a.bias, 8)) && cm_aligned(a.ln_g, 16) && cm_aligned(a.ln_b, 16)) {
         constexpr int TT = 32;
         const dim3 grid((a.seqlen + TT - 1) / TT, a.batch);

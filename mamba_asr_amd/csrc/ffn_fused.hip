@@ -18,7 +18,6 @@
 #include "cm_common.h"
 #include <type_traits>
 
-extern "C" int cm_debug_get();
 
 namespace {
 
@@ -503,6 +502,7 @@ int launch_var(const cm_ffn_args &a) {
 
 template <bool ADD>
 int launch(const cm_ffn_args &a) {
+#ifdef CM_ABLATE
     if (a.proj_w) return cm_debug_get() == 26 ? launch_var<ADD, 26, true>(a) : (cm_debug_get() == 25 ? launch_var<ADD, 25, true>(a) : launch_var<ADD, 0, true>(a));
     switch (cm_debug_get()) {
         case 1: return launch_var<ADD, 1>(a);
@@ -514,6 +514,9 @@ int launch(const cm_ffn_args &a) {
         case 26: return launch_var<ADD, 26>(a);
         default: return launch_var<ADD, 0>(a);
     }
+#else
+    return a.proj_w ? launch_var<ADD, 0, true>(a) : launch_var<ADD, 0>(a);
+#endif
 }
 
 }  // namespace

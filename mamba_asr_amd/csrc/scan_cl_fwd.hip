@@ -361,7 +361,9 @@ __global__ __launch_bounds__(64 * (16 / NS + 1)) void scan_cl_fwd_kernel(const c
     }
 }
 
+#ifdef CM_ABLATE
 std::atomic<int> g_debug{0};
+#endif
 
 template <typename IO, int NS, int TB>
 int launch(const cm_scan_cl_args &a) {
@@ -376,6 +378,7 @@ int launch(const cm_scan_cl_args &a) {
         vec_ok = vec_ok && cm_aligned(d.u, 16) && d.u_bs % VEC == 0 && d.u_ts % VEC == 0;
         if (!d.dt_low) vec_ok = vec_ok && cm_aligned(d.delta, 16) && d.delta_bs % VEC == 0 && d.delta_ts % VEC == 0;
     }
+#ifdef CM_ABLATE
     if constexpr (sizeof(IO) == 2 && NS == 2) {       // ablation builds exist for the bf16 NS=2 kernel only
         switch (g_debug.load()) {
             case 1: hipLaunchKernelGGL((scan_cl_fwd_kernel<IO, NS, TB, 1>), grid, block, 0, st, a, vec_ok); return cm_launch_status("abl1");
@@ -385,6 +388,7 @@ int launch(const cm_scan_cl_args &a) {
             default: break;
         }
     }
+#endif
     hipLaunchKernelGGL((scan_cl_fwd_kernel<IO, NS, TB, 0>), grid, block, 0, st, a, vec_ok);
     return cm_launch_status("cm_scan_cl_fwd");
 }
@@ -399,14 +403,15 @@ int by_split(const cm_scan_cl_args &a, int ns) {
 
 }  // namespace
 
-int cm_scan_split_override();
 int cm_scan_rows_fwd(const cm_scan_cl_args &a);      // scan_rows_fwd.hip
 
+#ifdef CM_ABLATE
 extern "C" int cm_debug_set(int v) { return g_debug.exchange(v); }
 extern "C" int cm_debug_get() { return g_debug.load(); }
 extern "C" int cm_debug_read_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
 }
+#endif
 
 extern "C" int cm_scan_cl_fwd(const cm_scan_cl_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "scan_cl_fwd: args is NULL");
@@ -431,7 +436,7 @@ extern "C" int cm_scan_cl_fwd(const cm_scan_cl_args *args) {
     }
     // states per lane: fewest waves that still give >= 2 waves per SIMD (2048 waves), else the finest split
     const long wg = (long)((a.dim + 63) / 64) * a.batch * a.ndir;
-    int lanes_per_channel = cm_scan_split_override();      // honours cm_scan_set_split / CM_SCAN_SPLIT: 4, 8, 16
+    const int lanes_per_channel = a.lanes_per_channel;     // tuning field: 4, 8, 16; 0 = automatic
     int ns;
     if (lanes_per_channel == 4 || lanes_per_channel == 8 || lanes_per_channel == 16) ns = 16 / lanes_per_channel;
     else ns = wg * 4 >= 2048 ? 4 : 2;

@@ -22,7 +22,6 @@
 #include "cm_common.h"
 #include <type_traits>
 
-extern "C" int cm_debug_get();
 
 namespace {
 
@@ -485,6 +484,7 @@ int launch_rows(const cm_scan_cl_args &a) {
             hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0, 32>), grid, block, 0, st, a, pl);
             return cm_launch_status("cm_scan_cl_fwd(rows, dt_rank 32)");
         }
+#ifdef CM_ABLATE
         switch (cm_debug_get()) {                       // ablation builds exist for the bf16 kernel only
             case 1: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 1>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl1");
             case 2: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 2>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl2");
@@ -493,6 +493,7 @@ int launch_rows(const cm_scan_cl_args &a) {
             case 5: hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 5>), grid, block, 0, st, a, pl); return cm_launch_status("rows abl5");
             default: break;
         }
+#endif
     }
     hipLaunchKernelGGL((scan_rows_fwd_kernel<IO, 0>), grid, block, 0, st, a, pl);
     return cm_launch_status("cm_scan_cl_fwd(rows)");

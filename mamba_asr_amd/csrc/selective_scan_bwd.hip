@@ -4,17 +4,16 @@
 int cm_scan_bwd_f32(const cm_scan_bwd_args &a, int S, bool vecok);
 int cm_scan_bwd_bf16(const cm_scan_bwd_args &a, int S, bool vecok);
 int cm_scan_bwd_bf16_f32(const cm_scan_bwd_args &a, int S, bool vecok);
-int cm_scan_pick_split(int batch, int dim, int dstate);
-int cm_scan_split_override();
+int cm_scan_pick_split(int batch, int dim, int dstate, int want);
 
 // lane split of the backward kernels (shared by the launch and the workspace query)
 static int bwd_split(const cm_scan_fwd_args &f) {
     // backward kernels exist for lane splits 4, 8, 16.  8 lanes per channel (2 states per lane) is the widest split that
     // still fits two waves per SIMD and beats 4 lanes (one wave per SIMD, 390 VGPRs) at every batch measured: 526 vs
-    // 572 us at 32 x 512 channels, 379 vs 547 us at 16; an explicit cm_scan_set_split still selects 4.
-    int S = cm_scan_pick_split(f.batch, f.dim, f.dstate);
+    // 572 us at 32 x 512 channels, 379 vs 547 us at 16; an explicit lanes_per_channel = 4 still selects 4.
+    int S = cm_scan_pick_split(f.batch, f.dim, f.dstate, f.lanes_per_channel);
     if (S < 4) S = 4;
-    if (S < 8 && cm_scan_split_override() == 0) S = 8;
+    if (S < 8 && f.lanes_per_channel == 0) S = 8;
     if (S > f.dstate) S = f.dstate;
     return S;
 }
@@ -39,6 +38,8 @@ extern "C" int cm_selective_scan_bwd(const cm_scan_bwd_args *args) {
                "scan_bwd: u/delta/A/B/C/x/dout must be non-NULL");
     CM_REQUIRE(a.du && a.ddelta && a.dA && a.dB && a.dC, CM_EINVAL, "scan_bwd: du/ddelta/dA/dB/dC must be non-NULL");
     CM_REQUIRE(!f.z || a.dz, CM_EINVAL, "scan_bwd: dz is NULL although z is given");
+    CM_REQUIRE(f.lanes_per_channel >= 0 && f.lanes_per_channel <= 16 && (f.lanes_per_channel & (f.lanes_per_channel - 1)) == 0, CM_EINVAL,
+               "scan_bwd: lanes_per_channel %d (0, 4, 8 or 16)", f.lanes_per_channel);
     CM_REQUIRE(f.h0 == nullptr, CM_EUNSUPPORTED, "scan_bwd: an initial state (h0) is a forward-only feature");
     const int vec = f.io_dtype == CM_F32 ? 4 : 8;
     auto rows_ok = [&](const void *p, int64_t s0, int64_t s1) {

@@ -136,11 +136,12 @@ def _fill_scan_args(a, u, delta, A, B, C_, D, z, delta_bias, delta_softplus, rev
 
 def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                        reverse=False, need_out=True, need_x=True, out_z_buf: Optional[torch.Tensor] = None,
-                       h0: Optional[torch.Tensor] = None):
+                       h0: Optional[torch.Tensor] = None, split: int = 0):
     """-> (out, x, out_z): what selective_scan_cuda.fwd returns (selective_scan_interface.py:42).
     ``out`` is the pre-gate output (None when z is given and need_out is False), ``x`` the
     checkpoint tensor (batch, dim, nchunks, 2*dstate) or None, ``out_z`` the gated output or None.
-    ``h0`` (batch, dim, dstate) fp32: state the recurrence starts from (time-split scans, seqpar.py)."""
+    ``h0`` (batch, dim, dstate) fp32: state the recurrence starts from (time-split scans, seqpar.py).
+    ``split``: tuning, lanes per channel (cm_scan_fwd_args.lanes_per_channel; 0 = the library's choice)."""
     _dev_check(u, delta, A, B, C, D, z, delta_bias)
     u, delta, z = _time_contig(u), _time_contig(delta), _time_contig(z)
     if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
@@ -168,6 +169,7 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
         h0 = _f32c(h0)
         a.h0 = _ptr(h0)
     a.out_bs, a.out_ds = d * l, l
+    a.lanes_per_channel = int(split)
     if out_z is not None:
         if out is not None and (out_z.stride(0), out_z.stride(1)) != (d * l, l):
             raise RuntimeError("out and a strided out_z_buf cannot be requested together (they share strides)")
@@ -178,7 +180,7 @@ def selective_scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 
 def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softplus=False, reverse=False,
                        dz: Optional[torch.Tensor] = None, recompute_out_z=False, du_buf: Optional[torch.Tensor] = None,
-                       ddelta_buf: Optional[torch.Tensor] = None, out_z_buf: Optional[torch.Tensor] = None):
+                       ddelta_buf: Optional[torch.Tensor] = None, out_z_buf: Optional[torch.Tensor] = None, split: int = 0):
     """-> (du, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z): the tuple selective_scan_cuda.bwd
     returns (selective_scan_interface.py:67, 252).  ``dz`` may be a pre-allocated view (e.g. half of
     dxz, :249-256).  dB/dC are fp32 (batch, 1, dstate, seqlen)."""
@@ -193,6 +195,7 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, delta_softp
     if x is None:
         raise RuntimeError("selective_scan_bwd needs the forward's checkpoint tensor x")
     a.fwd.x = _ptr(x)
+    a.fwd.lanes_per_channel = int(split)
     out_z = None
     def _buf(t, what):                       # optional pre-allocated time-contiguous (batch, dim, seqlen) views
         if t is None:
@@ -348,7 +351,7 @@ def _scan_cl_dir_rows(x, dd, u0, z, keep):
 SCAN_CHUNKS = os.environ.get("CM_SCAN_CHUNKS", "auto")
 
 
-def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None):
+def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split: int = 0):
     """Channels-last selective scan, 1 or 2 directions in one launch (cm_scan_cl_fwd).
     ``time_chunks`` (xdbl mode): None = the CM_SCAN_CHUNKS policy, else the chunk count.
 
@@ -408,6 +411,7 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None):
         x.reverse_time = int(bool(dd.get("reverse", False)))
         outs.append(out)
     a.stream = _stream()
+    a.lanes_per_channel = int(split)                     # tuning of the state-split kernel: 4, 8, 16 lanes per channel; 0 = automatic
     if "xdbl" in directions[0]:
         if time_chunks is None:
             time_chunks = (N.lib().cm_scan_cl_fwd_auto_chunks(b, l, d, len(directions)) if SCAN_CHUNKS == "auto"
@@ -424,7 +428,7 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None):
     return outs
 
 
-def conv_xproj(x, weight_f, bias_f, weight_b, bias_b, wx_f, wx_b, out_f, out_b, xdbl=None):
+def conv_xproj(x, weight_f, bias_f, weight_b, bias_b, wx_f, wx_b, out_f, out_b, xdbl=None, variant: int = 0):
     """Both directions' depthwise conv + SiLU and x_proj GEMMs in one kernel (cm_conv_xproj, bf16).
     x (batch, seqlen, dim) view; conv weights (dim, 4) fp32; wx_f / wx_b PackedWeight of the (P + 32, dim) re-rowed x_proj
     weights [dt P | B | C], P = 16, or 32 for 16 < dt_rank <= 32; out_f / out_b (batch, seqlen, dim) views.
@@ -448,7 +452,7 @@ def conv_xproj(x, weight_f, bias_f, weight_b, bias_b, wx_f, wx_b, out_f, out_b, 
     a.wx_f, a.wx_b, a.y_fwd, a.y_bwd, a.xdbl = _ptr(wx_f.data), _ptr(wx_b.data), _ptr(out_f), _ptr(out_b), _ptr(xdbl)
     a.x_bs, a.x_ts, a.yf_bs, a.yf_ts = x.stride(0), x.stride(1), out_f.stride(0), out_f.stride(1)
     a.yb_bs, a.yb_ts, a.xdbl_bs, a.xdbl_ts = out_b.stride(0), out_b.stride(1), xdbl.stride(0), xdbl.stride(1)
-    a.stream, a.dt_pad = _stream(), rw - 32
+    a.stream, a.dt_pad, a.variant = _stream(), rw - 32, int(variant)     # variant 1: always the 16-step tiles
     _launch("cm_conv_xproj", N.lib().cm_conv_xproj, a, units=b * l)
     return xdbl
 
@@ -754,7 +758,8 @@ def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):
     return out
 
 
-def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None, glu_done=False, lin_w=None, lin_b=None):
+def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t=None, glu_done=False, lin_w=None, lin_b=None,
+                       variant: int = 0):
     """(batch, seqlen, 2*dim) -> (batch, seqlen, dim): GLU, depthwise conv (k=31, same padding), LayerNorm, GELU
     (cm_glu_dwconv_ln_gelu).  weight (dim, 1, k) or (dim, k); weight_t: optional precomputed fp32 (k, dim) copy of the
     taps (made here per call otherwise) so that the kernel's per-channel tap reads are coalesced."""
@@ -778,7 +783,7 @@ def glu_dwconv_ln_gelu(inp, weight, bias, ln_weight, ln_bias, eps=1e-5, weight_t
             raise RuntimeError("glu_dwconv_ln_gelu: lin_w must be a PackedWeight of shape (dim, dim), with lin_b")
         lb = _f32c(lin_b)
         a.lin_w, a.lin_b = _ptr(lin_w.data), _ptr(lb)
-    a.stream = _stream()
+    a.stream, a.variant = _stream(), int(variant)        # variant 1: always the generic 16-step kernel
     _launch("cm_glu_dwconv_ln_gelu", N.lib().cm_glu_dwconv_ln_gelu, a, units=b * l)
     return out
 

@@ -14,21 +14,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def native():
     import mamba_asr_amd._native as N
     if not os.path.exists(N.LIB_PATH):
-        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "mamba-asr_amd", "csrc")])
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "mamba_asr_amd", "csrc")])
     return N
 
 
 def test_header_symbols_exported(native):
     hdr = open(os.path.join(ROOT, "include", "conmamba_hip.h")).read()
+    hdr = re.sub(r"#ifdef CM_ABLATE.*?#endif", "", hdr, flags=re.S)      # the ablation build's switch is not part of the product ABI
     declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char \*)\s*\*?\s*(cm_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert {"cm_selective_scan_fwd", "cm_selective_scan_bwd", "cm_causal_conv1d_fwd", "cm_causal_conv1d_bwd",
-            "cm_abi_version", "cm_last_error", "cm_scan_num_chunks", "cm_scan_set_split", "cm_debug_set", "cm_debug_get", "cm_scan_cl_fwd", "cm_conv_cl_fwd", "cm_conv_xproj", "cm_fbank_wav", "cm_cnn_front", "cm_ln_pw_glu", "cm_dwconv1d_fwd", "cm_dwconv1d_bwd", "cm_dwconv_cl_fwd", "cm_dwconv_cl_bwd", "cm_dwconv_cl_workspace_floats", "cm_causal_conv1d_update", "cm_selective_state_update", "cm_add_layernorm", "cm_layernorm_fwd", "cm_layernorm_bwd", "cm_layernorm_bwd_workspace_floats",
+            "cm_abi_version", "cm_last_error", "cm_scan_num_chunks", "cm_scan_cl_fwd", "cm_conv_cl_fwd", "cm_conv_xproj", "cm_fbank_wav", "cm_cnn_front", "cm_ln_pw_glu", "cm_dwconv1d_fwd", "cm_dwconv1d_bwd", "cm_dwconv_cl_fwd", "cm_dwconv_cl_bwd", "cm_dwconv_cl_workspace_floats", "cm_causal_conv1d_update", "cm_selective_state_update", "cm_add_layernorm", "cm_layernorm_fwd", "cm_layernorm_bwd", "cm_layernorm_bwd_workspace_floats",
             "cm_glu_dwconv_ln_gelu", "cm_cnn_block1", "cm_gemm_bf16", "cm_fbank_mel_db", "cm_fbank_finish",
             "cm_spec_drop"} <= declared
     handle = C.CDLL(native.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in conmamba_hip.h but not exported"
     assert {s[0] for s in native.SYMBOLS} == declared
+    # the product library carries no process-global switch (ablation variants live in the CM_ABLATE build only)
+    for name in ("cm_debug_set", "cm_debug_get", "cm_scan_set_split"):
+        assert not hasattr(handle, name), f"{name} must not be exported by the product library"
 
 
 def test_abi_version_and_chunks(native):

@@ -324,11 +324,8 @@ def test_dwconv_rows_kernel(D, batch, seqlen):
     torch.testing.assert_close(a.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
     torch.testing.assert_close(c.float().cpu(), ref, rtol=1.6e-2, atol=1e-2)
     assert (c.float().cpu() - ref).abs().mean() < 1.5e-3
-    _native.lib().cm_debug_set(31)                                # the 16-step kernel
-    try:
-        old = ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt), glu_done=True)
-    finally:
-        _native.lib().cm_debug_set(0)
+    old = ops.glu_dwconv_ln_gelu(dev(gated), dev(w), dev(bs), dev(lg), dev(lb), 1e-5, weight_t=dev(wt), glu_done=True,
+                                 variant=1)                   # the 16-step kernel
     torch.testing.assert_close(c.float(), old.float(), rtol=8e-3, atol=2e-3)       # fp32 sums in a different order, one bf16 rounding
     # the module's closing Linear in the same kernel (dim 256) == the kernel's bf16 activations through a fp32 matmul
     lw, lbias = (torch.randn(D, D, generator=g) / 16).bfloat16(), torch.randn(D, generator=g) * 0.1

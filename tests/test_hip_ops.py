@@ -33,12 +33,7 @@ def test_scan_fwd_golden(ops, golden, tag, split):
     u, dl, A, B, C, D, z, bias = gpu(*[g[f"{tag}_{k}"] for k in ("u", "delta", "A", "B", "C", "D", "z", "bias")])
     if split > A.shape[1]:
         pytest.skip("split larger than dstate")
-    from mamba_asr_amd import _native
-    prev = _native.lib().cm_scan_set_split(split)        # 0 = automatic choice
-    try:
-        out, x, out_z = ops.selective_scan_fwd(u, dl, A, B, C, D, z, bias, True)
-    finally:
-        _native.lib().cm_scan_set_split(prev)
+    out, x, out_z = ops.selective_scan_fwd(u, dl, A, B, C, D, z, bias, True, split=split)      # 0 = automatic choice
     close(out_z, g[f"{tag}_out_full"], 2e-4, 5e-5)
     close(x[:, :, -1, 1::2], g[f"{tag}_last_full"], 2e-4, 5e-5)       # ssi.py:45 contract
     close(out * torch.nn.functional.silu(z), g[f"{tag}_out_full"], 2e-4, 5e-5)
@@ -204,11 +199,7 @@ def test_scan_channels_last_two_directions(ops, shape, dtype, split):
         gB.copy_(Bm), gC.copy_(Cm)
         dirs.append(dict(u=u.to(DEV), delta=dl.to(DEV), A=A.to(DEV), B=gB, C=gC, D=D.to(DEV), delta_bias=bias.to(DEV),
                          out=ycat[:, :, i * e:(i + 1) * e], reverse=rev))
-    prev = _native.lib().cm_scan_set_split(split)
-    try:
-        ops.scan_cl_fwd(dirs, z=z.to(DEV) if False else xz.to(DEV)[:, :, e:], delta_softplus=True)
-    finally:
-        _native.lib().cm_scan_set_split(prev)
+    ops.scan_cl_fwd(dirs, z=xz.to(DEV)[:, :, e:], delta_softplus=True, split=split)
     tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
     close(ycat[:, :, :e].float(), refs[0], *tol)
     close(ycat[:, :, e:].float(), refs[1], *tol)
@@ -389,13 +380,9 @@ def test_conv_xproj(ops, shape, rw):
         close(xdbl[:, :, rw * i:rw * (i + 1)].float(), want, 1.6e-2, 2e-2)
     assert xdbl.shape == (b, l, 2 * rw)
     if b * ((l + 31) // 32) >= 512:
-        from mamba_asr_amd import _native
         u16 = torch.zeros_like(ucat)
-        _native.lib().cm_debug_set(16)
-        try:
-            x16 = ops.conv_xproj(x, wf, bf, wb, bb, ops.PackedWeight(wx[0]), ops.PackedWeight(wx[1]), out_f=u16[:, :, :e], out_b=u16[:, :, e:])
-        finally:
-            _native.lib().cm_debug_set(0)
+        x16 = ops.conv_xproj(x, wf, bf, wb, bb, ops.PackedWeight(wx[0]), ops.PackedWeight(wx[1]), out_f=u16[:, :, :e], out_b=u16[:, :, e:],
+                             variant=1)                      # the 16-step tiles
         assert torch.equal(u16, ucat) and torch.equal(x16, xdbl)
 
 

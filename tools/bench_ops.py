@@ -45,26 +45,24 @@ def main():
     bytes_fwd = b * l * (4 * e + 2 * n) * s
     lib = _native.lib()
     for split in (0, 1, 2, 4, 8, 16):
-        lib.cm_scan_set_split(split)
-        ms = timeit(lambda: ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False, need_x=False))
-        ms_r = timeit(lambda: ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, reverse=True, need_out=False, need_x=False))
+        ms = timeit(lambda: ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False, need_x=False, split=split))
+        ms_r = timeit(lambda: ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, reverse=True, need_out=False, need_x=False, split=split))
         print(f"scan_fwd split={split:2d}: fwd {ms*1e3:8.1f} us  rev {ms_r*1e3:8.1f} us  {bytes_fwd/ms/1e6:8.1f} GB/s "
               f"= {bytes_fwd/ms/1e6/8000*100:5.1f}% of 8 TB/s")
-    lib.cm_scan_set_split(0)
     # both directions concurrently on two streams
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cur = [0]
     def both():
         s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s1):
-            ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False, need_x=False)
+            ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False, need_x=False, split=cur[0])
         with torch.cuda.stream(s2):
-            ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, reverse=True, need_out=False, need_x=False)
+            ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, reverse=True, need_out=False, need_x=False, split=cur[0])
         torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
     for split in (0, 4, 8, 16):
-        lib.cm_scan_set_split(split)
+        cur[0] = split
         ms = timeit(both)
         print(f"scan_fwd both directions on 2 streams, split={split}: {ms*1e3:8.1f} us  {2*bytes_fwd/ms/1e6:8.1f} GB/s")
-    lib.cm_scan_set_split(0)
     # channels-last, both directions in one launch
     ucl, dcl = u.transpose(1, 2).contiguous(), delta.transpose(1, 2).contiguous()
     xz = torch.randn(b, l, 2 * e, device=dev, generator=g).to(dt)
@@ -74,18 +72,14 @@ def main():
     dirs = [dict(u=ucl, delta=dcl, A=A, B=Bcl, C=Ccl, D=D, delta_bias=bias, out=ycat[:, :, i * e:(i + 1) * e], reverse=bool(i))
             for i in range(2)]
     for split in (4, 8, 16):
-        lib.cm_scan_set_split(split)
-        ms = timeit(lambda: ops.scan_cl_fwd(dirs, z=xz[:, :, e:]))
+        ms = timeit(lambda: ops.scan_cl_fwd(dirs, z=xz[:, :, e:], split=split))
         print(f"scan_cl_fwd both directions one launch, lanes/channel={split:2d}: {ms*1e3:8.1f} us  {2*bytes_fwd/ms/1e6:8.1f} GB/s "
               f"= {2*bytes_fwd/ms/1e6/8000*100:5.1f}% of 8 TB/s")
-    lib.cm_scan_set_split(0)
     _, x, _ = ops.selective_scan_fwd(u, delta, A, B, C, D, z, bias, True, need_out=False)
     dout = torch.randn(b, e, l, device=dev, generator=g).to(dt)
     for split in (4, 8, 16):
-        lib.cm_scan_set_split(split)
-        ms = timeit(lambda: ops.selective_scan_bwd(u, delta, A, B, C, D, z, bias, dout, x, True), iters=5)
+        ms = timeit(lambda: ops.selective_scan_bwd(u, delta, A, B, C, D, z, bias, dout, x, True, split=split), iters=5)
         print(f"scan_bwd split={split:2d}: {ms*1e3:8.1f} us")
-    lib.cm_scan_set_split(0)
     if dt == torch.bfloat16:
         rows = b * l
         for (n_, k_, epi) in ((1024, 256, 1), (256, 1024, 2), (1024, 256, 0), (512, 256, 0), (256, 256, 2)):
