@@ -105,7 +105,9 @@ class Brain:
             else:
                 params = [p for p in self.modules.parameters() if p.grad is not None]
                 norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-            if torch.isfinite(norm) and torch.isfinite(loss):
+            if torch.isfinite(norm) and torch.isfinite(loss):     # the one host wait of a step (speechbrain's check_gradients does the same)
+                if self.reducer is not None:
+                    self.reducer.hide_unused()           # parameters without a gradient this step: .grad None, as after set_to_none
                 self.optimizer.step()
                 self.optimizer_step += 1
             if self.reducer is not None:

@@ -415,6 +415,38 @@ def decoder(p, tgt, memory, num_layers, prefix="", scan=selective_scan, act=F.re
     return _ln(tgt, p[prefix + "norm.norm.weight"].to(tgt.dtype), p[prefix + "norm.norm.bias"].to(tgt.dtype), 1e-6)
 
 
+def positional_encoding(length: int, d_model: int, dtype=torch.float32) -> torch.Tensor:
+    """PositionalEncoding, Transformer.py:992-1022: pe[t, 2i] = sin(t / 10000^(2i/d)), pe[t, 2i+1] = cos(...); the table
+    is built in fp32 (positions * exp(arange * -(ln 10000 / d))) exactly as the reference builds it; returns (1, length, d)."""
+    pe = torch.zeros(length, d_model)
+    pos = torch.arange(0, length).unsqueeze(1).float()
+    den = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * den)
+    pe[:, 1::2] = torch.cos(pos * den)
+    return pe.unsqueeze(0).to(dtype)
+
+
+def transformer_asr_forward(p, src, tgt, num_enc, num_dec, prefix="", scan=selective_scan, act=F.gelu):
+    """TransformerASR.forward with encoder_module 'conmamba', decoder_module 'mamba', attention_type 'RelPosMHAXL'
+    (TransformerASR.py:745-819), eval mode: 4-D src is flattened (:760-762), custom_src_module = Linear (+ Dropout)
+    (:727-735), no positional encoding on src in the RelPosMHAXL branch (:777-778: computed, unused by ConMamba), the
+    ConMamba encoder ignores every mask (Conmamba.py:631-635); tgt -> NormalizedEmbedding = Embedding * sqrt(d_model)
+    (Transformer.py:1851-1860) + PositionalEncoding (TransformerASR.py:793-796) -> MambaDecoder (masks unused,
+    Conmamba.py:914-953).  -> (encoder_out, decoder_out)."""
+    if src.dim() == 4:
+        src = src.reshape(src.shape[0], src.shape[1], -1)
+    x = F.linear(src, p[prefix + "custom_src_module.layers.0.w.weight"].to(src.dtype),
+                 p[prefix + "custom_src_module.layers.0.w.bias"].to(src.dtype))
+    enc = encoder(p, x, num_enc, prefix + "encoder.", scan)
+    if num_dec == 0:
+        return enc, None
+    emb = p[prefix + "custom_tgt_module.layers.0.emb.Embedding.weight"].to(src.dtype)
+    d_model = emb.shape[1]
+    t = F.embedding(tgt.long(), emb) * math.sqrt(d_model)
+    t = t + positional_encoding(t.shape[1], d_model, t.dtype)
+    return enc, decoder(p, t, enc, num_dec, prefix + "decoder.", scan, act)
+
+
 def mamba_step(p, hidden, conv_state, ssm_state, prefix=""):
     """One decoding step, restating the pure-torch fallback of reference modules/mamba/bimamba.py:320-365.
     hidden (b, 1, d); conv_state (b, e, w) and ssm_state (b, e, n) are updated in place.  -> out (b, 1, d)."""

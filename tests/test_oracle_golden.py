@@ -194,3 +194,38 @@ def test_step_decode(golden):
     close(ssm_state, g["ssm_state"], 1e-4, 1e-5)
     # and the token-by-token decode equals the full-sequence unidirectional forward (what f2 promises)
     close(torch.cat(outs, 1), O.mamba_uni(p, x), 1e-3, 1e-4)
+
+
+def _s2s_shapes():
+    from mamba_asr_amd.modules.TransformerASR import TransformerASR
+    m = TransformerASR(tgt_vocab=53, input_size=640, d_model=128, nhead=4, num_encoder_layers=2, num_decoder_layers=2, d_ffn=256,
+                       dropout=0.0, activation=torch.nn.GELU, encoder_module="conmamba", decoder_module="mamba",
+                       attention_type="RelPosMHAXL", normalize_before=True, causal=False,
+                       mamba_config={"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True})
+    return m, {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith(".pe")}     # parameters, not the sinusoid buffer
+
+
+def test_s2s_forward_restatement_and_host_modules(golden):
+    """The reference's own TransformerASR.forward / decode / encode (ConMamba encoder + Mamba decoder; golden made by
+    tests/golden/make_golden_r3.py): (i) the oracle's restatement, (ii) this package's host-side modules
+    (NormalizedEmbedding, PositionalEncoding, the state_dict key names) on the CPU — the reference's state_dict keys are
+    exactly this module's keys, so synth_like gives both the same parameters."""
+    S = _synth()
+    g = golden("g_s2s_forward")
+    m, shapes = _s2s_shapes()
+    p = S.synth_state(shapes, 1280)
+    src = S.synth_input("g_s2s.src", (3, 41, 20, 32), 1280)
+    tgt = g["tgt"].long()
+    enc, dec = O.transformer_asr_forward(p, src, tgt, 2, 2, scan=O.selective_scan_c)
+    close(enc, g["encoder_out"], 1e-3, 1e-4)
+    close(enc, g["encode_out"], 1e-3, 1e-4)
+    close(dec, g["decoder_out"], 1e-3, 1e-4)
+    close(dec, g["decode_prediction"], 1e-3, 1e-4)
+    # host-side pieces of the product, no kernels involved: embedding * sqrt(d) + positional table
+    miss = m.load_state_dict(p, strict=False)
+    assert not miss.unexpected_keys and all(k.endswith(".pe") for k in miss.missing_keys)      # same key names as the reference
+    t = m.custom_tgt_module(tgt)
+    t = t + m.positional_encoding_decoder(t)
+    emb = p["custom_tgt_module.layers.0.emb.Embedding.weight"]
+    want = torch.nn.functional.embedding(tgt, emb) * 128 ** 0.5 + O.positional_encoding(11, 128)
+    assert torch.equal(t, want)
