@@ -366,9 +366,9 @@ def main():
         torch.cuda.synchronize()
         ncopy = max(2, int(1.5 * host_s / max(c0.elapsed_time(c1) * 1e-3, 1e-5)) + 1)
         # An event pair around a launch also spans the dispatch of a dependent kernel and the end-of-kernel signal, which
-        # rocprofv3's kernel timestamps do not (+11-14 us here).  The same pair around a one-element kernel, queued behind
-        # the same step, measures that constant; it is reported and taken off the scan's interval.
-        tiny = torch.zeros(1, device=dev)
+        # rocprofv3's kernel timestamps do not.  An EMPTY pair (two records back to back, queued behind the same step) measures
+        # what the pair itself spans; that is reported and taken off the scan's interval (round 2 put a one-element kernel
+        # between the records and so also subtracted that kernel's ~2 us of run time: frac 0.261 against rocprofv3's 0.257).
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3 * 8)]
         ops.LAUNCH_LOG = []
         for rep in range(3):
@@ -376,13 +376,12 @@ def main():
                 blk[0].copy_(blk[1])
             eager_step()
             for q0, q1 in pairs[8 * rep:8 * rep + 8]:
-                q0.record()
-                tiny.add_(1.0)
-                q1.record()
+                q0.record()                                   # nothing between the two records: the interval an event pair
+                q1.record()                                   # itself spans in this queue (not a kernel's run time)
         torch.cuda.synchronize()
         log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
         pair_ms = sorted(q0.elapsed_time(q1) for q0, q1 in pairs)
-        pair_overhead_ms = pair_ms[len(pair_ms) // 2]                                          # median: interval of a ~2 us kernel
+        pair_overhead_ms = pair_ms[len(pair_ms) // 2]                                          # median of the empty intervals
         del blk
         scans = [(e0.elapsed_time(e1), units) for name, e0, e1, units in log if name == "cm_scan_cl_fwd"]
         if scans:

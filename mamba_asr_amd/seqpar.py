@@ -254,7 +254,7 @@ def encoder_forward_seq_parallel_fused(encoder, src_shard, group):
     batch, T, D = src_shard.shape
     caches = [fused._cache(layer, dtype) for layer in encoder.layers]
     for layer, c in zip(encoder.layers, caches):
-        if not (fused.supports(layer) and ops.ffn_supported(D, c.ffn1["w1"].shape[0], dtype) and c.rows_mode and c.wx_packed is not None
+        if not (fused.supports(layer) and ops.ffn_supported(D, c.ffn1["w1"].shape[0], dtype) and c.rows_mode and c.row_width == 48 and c.wx_packed is not None
                 and c.pw_packed is not None and c.in_bias is None and c.out_bias is None and c.gamma is None):
             raise NotImplementedError("layer outside the fused bf16 route (d_model 256, dt_rank <= 16): use encoder_forward_seq_parallel")
     dev = src_shard.device
