@@ -115,12 +115,15 @@ def test_training_step_loss_and_every_gradient_vs_oracle():
     print(f"training step, fp32: CTC oracle(fp64) {float(ref_loss):.6f} gpu {float(loss):.6f} |delta| {d:.2e}")
     assert d <= 1e-3
     assert set(grads) == set(ref), sorted(set(grads) ^ set(ref))
-    worst = 0.0
-    for k in ref:
-        close(grads[k], ref[k], rtol=5e-3, atol=5e-4)
-        worst = max(worst, rel_l2(grads[k], ref[k]))
-    print(f"  {len(ref)} parameter gradients, worst relative L2 error {worst:.2e}")
-    assert worst < 2e-3
+    # every gradient: relative L2 error <= 2e-3 and every element within 2e-3 of the tensor's largest |gradient| (G3 / G4's
+    # bounds; the elementwise bound is relative to the tensor's scale because single elements of the input-most tensors -- the
+    # CNN front end's taps, behind two LeakyReLU kinks and 2 x 18 kernels -- sit next to an activation kink in fp32 vs fp64)
+    stats = {k: (rel_l2(grads[k], ref[k]), float((grads[k].double().cpu() - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-30)))
+             for k in ref}
+    top = sorted(stats.items(), key=lambda kv: -kv[1][0])[:5]
+    print(f"  {len(ref)} parameter gradients; worst relative L2 errors: " + ", ".join(f"{k} {v[0]:.1e}" for k, v in top))
+    bad = {k: v for k, v in stats.items() if v[0] > 2e-3 or v[1] > 2e-3}
+    assert not bad, bad
     # bf16 autocast (the recipe's precision, conmamba_large.yaml:86): looser
     loss_bf, grads_bf, _ = _gpu_loss_and_grads(model, wavs, lens, tokens, tok_lens, autocast=True)
     dbf = abs(float(loss_bf) - float(ref_loss))
@@ -132,9 +135,23 @@ def test_training_step_loss_and_every_gradient_vs_oracle():
     assert not bad, bad
 
 
+def _same_grads(a, b, names):
+    """Bit-equal outside the CNN front end; the front end's conv2d backward is the vendor library's (MIOpen weight / data
+    gradient kernels accumulate with atomics: last-bit differences from run to run) -- its four tensors within 1e-5 of
+    their scale.  The encoder, the src Linear and the CTC head run on this package's deterministic kernels."""
+    ok = True
+    for k, x, y in zip(names, a, b):
+        if k.startswith("CNN."):
+            ok = ok and float((x - y).abs().max()) <= 1e-5 * float(y.abs().max().clamp_min(1e-30))
+        else:
+            ok = ok and torch.equal(x, y)
+    return ok
+
+
 def test_training_step_gradients_are_bit_reproducible():
-    """Everything below the CTC loss's own backward (torch's kernel accumulates with atomics) is deterministic: with the
-    gradient of the log-probabilities held fixed, two backward passes give bit-identical parameter gradients."""
+    """Everything between the CNN front end (vendor conv2d backward) and the CTC loss's own backward (torch's kernel
+    accumulates with atomics) is deterministic: with the gradient of the log-probabilities held fixed, two backward passes
+    give bit-identical gradients for every encoder / projection / head parameter."""
     cfg, model, wavs, lens, tokens, tok_lens = _train_case(batch=2, frames=200)
     runs = []
     g = None
@@ -146,7 +163,9 @@ def test_training_step_gradients_are_bit_reproducible():
             g = torch.randn(logp.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 1e-2
         logp.backward(g)
         runs.append({k: p.grad.clone() for k, p in model.named_parameters()})
-    assert all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
+    names = list(runs[0])
+    assert _same_grads([runs[0][k] for k in names], [runs[1][k] for k in names], names)
+    assert sum(not k.startswith("CNN.") for k in names) >= 90
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -160,10 +179,11 @@ import torch, torch.distributed as dist
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("CM_PORT", "29533"), RANK="0", WORLD_SIZE="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
-from test_hip_parity_r3 import _train_case, DEV
+from test_hip_parity_r3 import _train_case, _same_grads, DEV
 from mamba_asr_amd.ddp import GradAllReducer
 cfg, model, wavs, lens, tokens, tok_lens = _train_case(batch=2, frames=200)
-params = [p for p in model.parameters() if p.requires_grad]
+named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+names, params = [k for k, _ in named], [p for _, p in named]
 gfix = None
 def step(autocast):
     global gfix
@@ -189,10 +209,11 @@ for autocast in (False, True):
             red.finish()
             torch.cuda.synchronize()
             key = f"{'bf16' if autocast else 'fp32'}-{algo}-{'bf16' if cdt else 'fp32'}"
-            if cdt is None:
-                out[key] = all(torch.equal(p.grad, q) for p, q in zip(params, plain))
+            got = [p.grad for p in params]
+            if cdt is None:                            # (the CNN front end's vendor conv backward: see _same_grads)
+                out[key] = _same_grads(got, plain, names)
             else:                                      # bf16 transport: the gradient rounded to bf16 once
-                out[key] = all(torch.equal(p.grad, q.bfloat16().float()) for p, q in zip(params, plain))
+                out[key] = _same_grads([x.bfloat16().float() for x in got], [q.bfloat16().float() for q in plain], names)
             out[key + "-views"] = all(p.grad.data_ptr() == red._view[p].data_ptr() for p in params)
             out[key + "-bytes"] = red.bytes_per_step()
             red.close()                                # remove this reducer's hooks before the next one registers its own
@@ -205,7 +226,8 @@ print("RESULT " + json.dumps(out))
 def test_training_step_under_world1_rccl_group(tmp_path):
     """GradAllReducer(always_exchange=True) over backend 'nccl' (= RCCL) at world size 1, in a child process (a process
     group in the pytest process would outlive the test): all-reduce and mesh (all-to-all + fixed-order sum + all-gather),
-    fp32 and bf16 transport, under fp32 and bf16-autocast compute.  fp32 transport: gradients BIT-EQUAL to plain autograd's."""
+    fp32 and bf16 transport, under fp32 and bf16-autocast compute.  fp32 transport: gradients BIT-EQUAL to plain autograd's
+    (encoder / projections / head; the vendor conv2d backward of the CNN front end is not bit-reproducible by itself)."""
     script = tmp_path / "child.py"
     script.write_text(_CHILD)
     env = dict(os.environ, CM_ROOT=ROOT, CM_PORT=str(29500 + os.getpid() % 400), HSA_ENABLE_IPC_MODE_LEGACY="0")
