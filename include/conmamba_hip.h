@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 6
+#define CM_ABI_VERSION 7
 
 /* error codes */
 #define CM_OK            0
@@ -232,6 +232,13 @@ typedef struct cm_scan_cl_dir {
     float       *h_last;     /* out: state after the last processed step                                               */
     float       *decay;      /* out: product over the sequence of exp(delta' A), i.e. what a state entering this shard
                                 is multiplied by on its way through it                                                */
+    /* xdbl mode only, optional: what the training forward saves for cm_scan_cl_bwd (the role of the checkpoint tensor `x`
+       of selective_scan_cuda.fwd, selective_scan_interface.py:42, on this kernel's 16-step blocks) */
+    float       *ckpt;       /* out: (batch, 2 ceil(seqlen / 16), dim, 16) fp32: the state the recurrence ENTERS each half
+                                block of 8 steps [8 m, 8 m + 8) with, in this direction's scan order (m < 2 ceil(seqlen/16);
+                                steps past seqlen pass the state through)                                            */
+    void        *ypre;       /* out: (batch, seqlen, dim), I/O dtype: the pre-gate output sum_n C h + D u              */
+    int64_t ypre_bs, ypre_ts;
 } cm_scan_cl_dir;
 
 typedef struct cm_scan_cl_args {
@@ -260,6 +267,54 @@ int cm_scan_cl_fwd(const cm_scan_cl_args *args);
 int64_t cm_scan_cl_fwd_workspace_bytes(const cm_scan_cl_args *args);
 /* the chunk count that fills 256 CUs for this problem size (1 = do not chunk); a pure function of the sizes */
 int32_t cm_scan_cl_fwd_auto_chunks(int32_t batch, int32_t seqlen, int32_t dim, int32_t ndir);
+
+/* ---------------------------------------------------------------------------------------
+ * Channels-last selective scan BACKWARD, both BiMamba directions in one launch (csrc/scan_rows_bwd.hip): the gradient
+ * of cm_scan_cl_fwd's xdbl mode with z and softplus -- selective_scan_cuda.bwd (selective_scan_interface.py:252-256)
+ * together with the dt_proj part of MambaInnerFnNoOutProj.backward (:258-283: ddelta -> d dt_proj.weight and the dt
+ * columns of dx_dbl), on the forward's layout: rows (batch * time, channels), x_dbl rows as the x_proj GEMM wrote them,
+ * no transposed copy.  Per direction:
+ *   in : u, xdbl, A, dt_weight (dim, P) fp32 zero padded, D, delta_bias (as the forward), ckpt and ypre written by the
+ *        forward, dout = gradient of the gated output; shared z
+ *   out: du (gradient w.r.t. u through the scan only: the x_proj path is added by the caller), dz (THIS direction's
+ *        share of dz: the caller adds the two), dxdbl (batch, seqlen, P + 32) in the I/O dtype = [d dt (P) | dB | dC],
+ *        and fp32 dA (dim, 16), ddt_weight (dim, P), dD (dim), ddelta_bias (dim), ACCUMULATED into.
+ * Every cross-workgroup sum (dxdbl over the channel groups, the parameter gradients over the batch) goes through the
+ * caller-owned workspace and a fixed-order second pass: bit-identical results from run to run.
+ * dim: multiple of 8 (bf16) / 4 (fp32); dstate 16; dt_rank <= 16, or <= 32 with bf16 I/O; strides in elements.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_scan_cl_bwd_dir {
+    const void  *u;          /* (batch, seqlen, dim)                                         */
+    const void  *xdbl;       /* (batch, seqlen, P + 32)                                      */
+    const float *A;          /* (dim, 16)                                                    */
+    const float *dt_weight;  /* (dim, P) fp32, zero padded                                   */
+    const float *D;          /* (dim) or NULL                                                */
+    const float *delta_bias; /* (dim) or NULL                                                */
+    const float *ckpt;       /* (batch, 2 ceil(seqlen / 16), dim, 16) from the forward      */
+    const void  *ypre;       /* (batch, seqlen, dim) from the forward                       */
+    const void  *dout;       /* (batch, seqlen, dim)                                         */
+    void        *du, *dz;    /* (batch, seqlen, dim)                                         */
+    void        *dxdbl;      /* (batch, seqlen, P + 32)                                      */
+    float       *dA, *ddt_weight, *dD, *ddelta_bias;   /* dD / ddelta_bias may be NULL      */
+    int64_t u_bs, u_ts, xdbl_bs, xdbl_ts, ypre_bs, ypre_ts, dout_bs, dout_ts, du_bs, du_ts, dz_bs, dz_ts, dxdbl_bs, dxdbl_ts;
+    int32_t reverse_time;
+    int32_t dt_rank;         /* P: 16 or 32                                                  */
+} cm_scan_cl_bwd_dir;
+
+typedef struct cm_scan_cl_bwd_args {
+    int32_t batch, seqlen, dim, dstate;
+    int32_t io_dtype;        /* CM_BF16 or CM_F32                                            */
+    int32_t ndir;            /* 1 or 2                                                       */
+    const void *z;           /* (batch, seqlen, dim), required                               */
+    int64_t z_bs, z_ts;
+    cm_scan_cl_bwd_dir dir[2];
+    void   *stream;
+    void   *workspace;       /* cm_scan_cl_bwd_workspace_bytes(args) bytes, 16-byte aligned  */
+    int64_t workspace_bytes;
+} cm_scan_cl_bwd_args;
+
+int64_t cm_scan_cl_bwd_workspace_bytes(const cm_scan_cl_bwd_args *args);
+int cm_scan_cl_bwd(const cm_scan_cl_bwd_args *args);
 
 /* ---------------------------------------------------------------------------------------
  * Channels-last causal conv, both BiMamba directions in one pass over x.

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -62,6 +62,7 @@ class ScanClDir(C.Structure):
         ("bc_ns", i64), ("bc_bs", i64), ("reverse_time", i32), ("dt_rank", i32),
         ("xdbl", vp), ("xdbl_bs", i64), ("xdbl_ts", i64),
         ("h0", fp), ("h_last", fp), ("decay", fp),
+        ("ckpt", fp), ("ypre", vp), ("ypre_bs", i64), ("ypre_ts", i64),
     ]
 
 
@@ -73,6 +74,25 @@ class ScanClArgs(C.Structure):
         ("dir", ScanClDir * 2),
         ("stream", vp),
         ("workspace", vp), ("workspace_bytes", i64), ("lanes_per_channel", i32), ("pad5_", i32),
+    ]
+
+
+class ScanClBwdDir(C.Structure):
+    _fields_ = [
+        ("u", vp), ("xdbl", vp), ("A", fp), ("dt_weight", fp), ("D", fp), ("delta_bias", fp), ("ckpt", fp), ("ypre", vp),
+        ("dout", vp), ("du", vp), ("dz", vp), ("dxdbl", vp), ("dA", fp), ("ddt_weight", fp), ("dD", fp), ("ddelta_bias", fp),
+        ("u_bs", i64), ("u_ts", i64), ("xdbl_bs", i64), ("xdbl_ts", i64), ("ypre_bs", i64), ("ypre_ts", i64),
+        ("dout_bs", i64), ("dout_ts", i64), ("du_bs", i64), ("du_ts", i64), ("dz_bs", i64), ("dz_ts", i64),
+        ("dxdbl_bs", i64), ("dxdbl_ts", i64), ("reverse_time", i32), ("dt_rank", i32),
+    ]
+
+
+class ScanClBwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32), ("io_dtype", i32), ("ndir", i32),
+        ("z", vp), ("z_bs", i64), ("z_ts", i64),
+        ("dir", ScanClBwdDir * 2),
+        ("stream", vp), ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -232,6 +252,8 @@ SYMBOLS = [
     ("cm_scan_cl_fwd", C.c_int, [C.POINTER(ScanClArgs)]),
     ("cm_scan_cl_fwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClArgs)]),
     ("cm_scan_cl_fwd_auto_chunks", i32, [i32, i32, i32, i32]),
+    ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
+    ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),

@@ -88,6 +88,10 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
                                                 ((int64_t)(T - 1) * x_ts + RW) * S);
     const __amdgpu_buffer_rsrc_t orr = make_rsrc(SUM ? nullptr : reinterpret_cast<IO *>(d.out) + (int64_t)b * d.out_bs + (int64_t)t_lo * o_ts,
                                                  SUM ? 0 : ((int64_t)(T - 1) * o_ts + E) * S);
+    const bool has_pre = !SUM && d.ypre != nullptr;          // training forward: pre-gate output for cm_scan_cl_bwd
+    const int p_ts = (int)d.ypre_ts;
+    const __amdgpu_buffer_rsrc_t prr = make_rsrc(has_pre ? reinterpret_cast<IO *>(d.ypre) + (int64_t)b * d.ypre_bs + (int64_t)t_lo * p_ts : nullptr,
+                                                 has_pre ? ((int64_t)(T - 1) * p_ts + E) * S : 0);
     const int tb0 = (REV ? nblk - 1 : 0) * TB;               // first block's base step; blocks advance by +-TB steps
     constexpr int DIR = REV ? -1 : 1;
 
@@ -171,6 +175,12 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     const float *red_r = patch + c16 * 16 + 4 * (g ^ (c16 >> 2));
     int o_off = c_ok ? ((tb0 + 4 * g) * o_ts + c) * S : 0x7fffffff;   // out-of-range offset: stores dropped
     const int o_step = c_ok ? DIR * TB * o_ts * S : 0;
+    int p_off = (c_ok && has_pre) ? ((tb0 + 4 * g) * p_ts + c) * S : 0x7fffffff;
+    const int p_step = (c_ok && has_pre) ? DIR * TB * p_ts * S : 0;
+    // training forward: the state each half block of 8 steps [8 m, 8 m + 8) is entered with (scan order),
+    // (batch, 2 ceil(seqlen / 16), dim, 16) fp32; ck points at the block's first time half
+    float *ck = (!SUM && d.ckpt && c_ok) ? d.ckpt + (((int64_t)b * 2 * ((p.seqlen + TB - 1) / TB) + 2 * ((t_lo + tb0) / TB)) * E + c) * 16 + 4 * g : nullptr;
+    const int64_t ck_step = (int64_t)DIR * 2 * E * 16, ck_half = (int64_t)E * 16;
 
     // delta' = softplus(W_dt . dt + bias), delta'*u for the block staged at (buf_tile, buf_x) -> per-wave patch;
     // owned (u, z) -> registers.  tb = the block's base step.
@@ -261,6 +271,12 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
             }
             step(2 * sg, q[sg & 1][0]);
             step(2 * sg + 1, q[sg & 1][1]);
+            if constexpr (!SUM) {
+                if (sg == TB / 4 - 1 && ck) {                         // 8 steps done: entry state of the block's second half (scan order)
+                    *reinterpret_cast<float4 *>(ck + (REV ? 0 : ck_half)) = make_float4(h01.x, h01.y, h23.x, h23.y);
+                    ck += ck_step;
+                }
+            }
             // pin the state here: machine-sink otherwise moves the whole h chain below the last scheduling barrier
             // (its results are only consumed at the end of the block) and keeps 64 exp results alive instead
             if constexpr (SUM) asm volatile("" : "+v"(h01), "+v"(h23));
@@ -286,10 +302,12 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float ov = fmaf(Dv, uq[i], y[i]);
+            if (has_pre) st_io(prr, p_off, i * p_ts * S, ov, IO{});
             if (has_z && ABL != 3) ov *= zq[i] * cm_sigmoid(zq[i]);
             st_io(orr, o_off, i * o_ts * S, ov, IO{});
         }
         o_off += o_step;
+        p_off += p_step;
     };
 
     // tile ring: byte offsets of the (u/z, x_dbl) tiles holding block k, k+1 and the one block k+2 is committed to
@@ -308,6 +326,9 @@ __device__ __forceinline__ void scan_rows(const cm_scan_cl_args &p, const cm_sca
     for (int k = 0; k < nblk; ++k) {
         const bool more = ABL != 5 && k + 2 < nblk;
         if (more) issue();
+        if constexpr (!SUM) {
+            if (ck) *reinterpret_cast<float4 *>(ck + (REV ? ck_half : 0)) = make_float4(h01.x, h01.y, h23.x, h23.y);
+        }
         const f32x4 y = recur(x_cur);
         if constexpr (!SUM) gate(y);
         tb += DIR * TB;

@@ -335,6 +335,20 @@ def _scan_cl_dir_rows(x, dd, u0, z, keep):
     x.u_bs, x.u_ts, x.out_bs, x.out_ts = u.stride(0), u.stride(1), out.stride(0), out.stride(1)
     x.xdbl_bs, x.xdbl_ts, x.dt_rank = xdbl.stride(0), xdbl.stride(1), pad
     x.reverse_time = int(bool(dd.get("reverse", False)))
+    ck, yp = dd.get("ckpt"), dd.get("ypre")                  # what the training forward saves for scan_cl_bwd
+    if ck is not None:
+        _dev_check(ck)
+        if ck.dtype != torch.float32 or not ck.is_contiguous() or tuple(ck.shape) != (b, 2 * ((l + 15) // 16), d, 16):
+            raise RuntimeError("xdbl mode: ckpt must be a contiguous fp32 (batch, 2 * ceil(seqlen / 16), dim, 16) tensor")
+        keep.append(ck)
+        x.ckpt = _ptr(ck)
+    if yp is not None:
+        _dev_check(yp)
+        _rows_ok(yp, "ypre")
+        if yp.shape != (b, l, d) or yp.dtype != u0.dtype:
+            raise RuntimeError("xdbl mode: ypre must be (batch, seqlen, dim) in the I/O dtype")
+        keep.append(yp)
+        x.ypre, x.ypre_bs, x.ypre_ts = _ptr(yp), yp.stride(0), yp.stride(1)
     for key in ("h0", "h_last", "decay"):                    # carry interface of the time-split scan: (batch, dim, 16) fp32
         t = dd.get(key)
         if t is not None:
@@ -425,6 +439,74 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split
     elif time_chunks not in (None, 0, 1):
         raise RuntimeError("time_chunks needs the xdbl mode")
     _launch("cm_scan_cl_fwd", N.lib().cm_scan_cl_fwd, a, units=b * l * len(directions))
+    return outs
+
+
+def scan_ckpt_shape(batch: int, seqlen: int, dim: int):
+    """Shape of the checkpoint tensor the training forward writes (cm_scan_cl_dir.ckpt)."""
+    return (batch, 2 * ((seqlen + 15) // 16), dim, 16)
+
+
+def scan_cl_bwd(directions, z):
+    """Channels-last selective scan backward, 1 or 2 directions in one launch (cm_scan_cl_bwd): the gradient of
+    scan_cl_fwd's xdbl mode (z and softplus on) including the dt_proj part.
+
+    ``directions``: list of dicts with u (batch, seqlen, dim), xdbl (batch, seqlen, P + 32), A (dim, 16), dt_weight (dim, P)
+    zero padded (pad_dt_weight), D, delta_bias (dim), ckpt and ypre as the forward wrote them, dout (batch, seqlen, dim),
+    reverse; optional pre-allocated du, dz, dxdbl views.  Returns a list of dicts du, dz (this direction's share), dxdbl
+    (I/O dtype, [d dt | dB | dC]), and fp32 dA (dim, 16), ddt_weight (dim, P), dD, ddelta_bias (dim)."""
+    if not 1 <= len(directions) <= 2:
+        raise RuntimeError("1 or 2 directions")
+    u0 = directions[0]["u"]
+    _dev_check(u0, z)
+    _rows_ok(u0, "u"), _rows_ok(z, "z")
+    b, l, d = u0.shape
+    if z.shape != (b, l, d) or z.dtype != u0.dtype:
+        raise RuntimeError("scan_cl_bwd: z must be (batch, seqlen, dim) in u's dtype")
+    a = N.ScanClBwdArgs()
+    a.batch, a.seqlen, a.dim, a.dstate, a.io_dtype, a.ndir = b, l, d, 16, _DT[u0.dtype], len(directions)
+    a.z, a.z_bs, a.z_ts = _ptr(z), z.stride(0), z.stride(1)
+    keep, outs = [], []
+    for i, dd in enumerate(directions):
+        u, xdbl, dout, ypre, ck = dd["u"], dd["xdbl"], dd["dout"], dd["ypre"], dd["ckpt"]
+        _dev_check(u, xdbl, dout, ypre, ck, dd["A"], dd["dt_weight"])
+        for t, nm in ((u, "u"), (xdbl, "xdbl"), (dout, "dout"), (ypre, "ypre")):
+            _rows_ok(t, nm)
+        pad = xdbl.shape[-1] - 32
+        if pad not in (16, 32) or (pad == 32 and u0.dtype != torch.bfloat16):
+            raise RuntimeError("scan_cl_bwd: xdbl rows are 48 wide, or 64 wide (dt_rank > 16) in bf16")
+        if any(t.shape != (b, l, d) or t.dtype != u0.dtype for t in (u, dout, ypre)) or xdbl.shape != (b, l, pad + 32) or xdbl.dtype != u0.dtype:
+            raise RuntimeError("scan_cl_bwd: u / dout / ypre (batch, seqlen, dim) and xdbl (batch, seqlen, 48 | 64) must share shape prefix and dtype")
+        if tuple(ck.shape) != scan_ckpt_shape(b, l, d) or ck.dtype != torch.float32 or not ck.is_contiguous():
+            raise RuntimeError("scan_cl_bwd: ckpt must be the contiguous fp32 tensor the forward wrote (ops.scan_ckpt_shape)")
+        dt_w = dd["dt_weight"]
+        if dt_w.shape != (d, pad):
+            raise RuntimeError(f"scan_cl_bwd: dt_weight must be (dim, {pad}), zero padded (ops.pad_dt_weight)")
+        A, D, bias, dt_w = _f32c(dd["A"]), _f32c(dd.get("D")), _f32c(dd.get("delta_bias")), _f32c(dt_w)
+        du = dd.get("du") if dd.get("du") is not None else torch.empty((b, l, d), dtype=u.dtype, device=u.device)
+        dz = dd.get("dz") if dd.get("dz") is not None else torch.empty((b, l, d), dtype=u.dtype, device=u.device)
+        dx = dd.get("dxdbl") if dd.get("dxdbl") is not None else torch.empty((b, l, pad + 32), dtype=u.dtype, device=u.device)
+        for t, nm in ((du, "du"), (dz, "dz"), (dx, "dxdbl")):
+            _rows_ok(t, nm)
+        dA = torch.zeros((d, 16), dtype=torch.float32, device=u.device)
+        dW = torch.zeros((d, pad), dtype=torch.float32, device=u.device)
+        dD = torch.zeros((d,), dtype=torch.float32, device=u.device) if D is not None else None
+        db = torch.zeros((d,), dtype=torch.float32, device=u.device) if bias is not None else None
+        keep += [A, D, bias, dt_w]
+        x = a.dir[i]
+        x.u, x.xdbl, x.A, x.dt_weight, x.D, x.delta_bias, x.ckpt, x.ypre, x.dout = (_ptr(u), _ptr(xdbl), _ptr(A), _ptr(dt_w), _ptr(D),
+                                                                                    _ptr(bias), _ptr(ck), _ptr(ypre), _ptr(dout))
+        x.du, x.dz, x.dxdbl, x.dA, x.ddt_weight, x.dD, x.ddelta_bias = _ptr(du), _ptr(dz), _ptr(dx), _ptr(dA), _ptr(dW), _ptr(dD), _ptr(db)
+        x.u_bs, x.u_ts, x.xdbl_bs, x.xdbl_ts = u.stride(0), u.stride(1), xdbl.stride(0), xdbl.stride(1)
+        x.ypre_bs, x.ypre_ts, x.dout_bs, x.dout_ts = ypre.stride(0), ypre.stride(1), dout.stride(0), dout.stride(1)
+        x.du_bs, x.du_ts, x.dz_bs, x.dz_ts, x.dxdbl_bs, x.dxdbl_ts = du.stride(0), du.stride(1), dz.stride(0), dz.stride(1), dx.stride(0), dx.stride(1)
+        x.reverse_time, x.dt_rank = int(bool(dd.get("reverse", False))), pad
+        outs.append(dict(du=du, dz=dz, dxdbl=dx, dA=dA, ddt_weight=dW, dD=dD, ddelta_bias=db))
+    a.stream = _stream()
+    nbytes = int(N.lib().cm_scan_cl_bwd_workspace_bytes(ct.byref(a)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=u0.device)
+    a.workspace, a.workspace_bytes = _ptr(ws), nbytes
+    _launch("cm_scan_cl_bwd", N.lib().cm_scan_cl_bwd, a, units=b * l * len(directions))
     return outs
 
 
