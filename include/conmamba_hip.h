@@ -337,6 +337,30 @@ typedef struct cm_conv_cl_args {
 
 int cm_conv_cl_fwd(const cm_conv_cl_args *args);
 
+/* Backward of cm_conv_cl_fwd / the conv half of cm_conv_xproj (both directions in one pass; replaces
+ * causal_conv1d_cuda.causal_conv1d_bwd, selective_scan_interface.py:286-288, run once per direction by the reference):
+ *   dx = dx_fwd + dx_bwd (the two directions share x: reference bimamba.py:223-248), pre-activations recomputed from x;
+ *   dz = dz_f + dz_b (the two directions' shares of the gate gradient, cm_scan_cl_bwd) when dz != NULL;
+ *   dweight_* (dim, 4), dbias_* (dim) fp32, ACCUMULATED into, summed in a fixed order through `workspace`.
+ * du_b == NULL: one direction (the unidirectional mixer of the Mamba decoder).  Strides in elements. */
+typedef struct cm_conv_cl_bwd_args {
+    int32_t batch, seqlen, dim, width;
+    int32_t io_dtype, pad_;
+    const void  *x;                                       /* (batch, seqlen, dim) view                       */
+    const float *weight_f, *bias_f, *weight_b, *bias_b;   /* (dim, 4) / (dim); biases may be NULL           */
+    const void  *du_f, *du_b;                             /* gradients of u_fwd / u_bwd                      */
+    const void  *dz_f, *dz_b;                             /* optional                                        */
+    void *dx, *dz;                                        /* outputs; dz optional                            */
+    float *dweight_f, *dbias_f, *dweight_b, *dbias_b;
+    int64_t x_bs, x_ts, duf_bs, duf_ts, dub_bs, dub_ts, dzf_bs, dzf_ts, dzb_bs, dzb_ts, dx_bs, dx_ts, dz_bs, dz_ts;
+    void *stream;
+    float *workspace;                                     /* cm_conv_cl_bwd_workspace_floats() floats       */
+    int64_t workspace_floats;
+} cm_conv_cl_bwd_args;
+
+int64_t cm_conv_cl_bwd_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);
+int cm_conv_cl_bwd(const cm_conv_cl_bwd_args *args);
+
 /* ---------------------------------------------------------------------------------------
  * cm_conv_cl_fwd for both directions fused with both directions' x_proj GEMMs (bf16 only):
  *   y_fwd, y_bwd as cm_conv_cl_fwd (SiLU applied), and

@@ -77,6 +77,18 @@ class ScanClArgs(C.Structure):
     ]
 
 
+class ConvClBwdArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("seqlen", i32), ("dim", i32), ("width", i32), ("io_dtype", i32), ("pad_", i32),
+        ("x", vp), ("weight_f", fp), ("bias_f", fp), ("weight_b", fp), ("bias_b", fp),
+        ("du_f", vp), ("du_b", vp), ("dz_f", vp), ("dz_b", vp), ("dx", vp), ("dz", vp),
+        ("dweight_f", fp), ("dbias_f", fp), ("dweight_b", fp), ("dbias_b", fp),
+        ("x_bs", i64), ("x_ts", i64), ("duf_bs", i64), ("duf_ts", i64), ("dub_bs", i64), ("dub_ts", i64),
+        ("dzf_bs", i64), ("dzf_ts", i64), ("dzb_bs", i64), ("dzb_ts", i64), ("dx_bs", i64), ("dx_ts", i64), ("dz_bs", i64), ("dz_ts", i64),
+        ("stream", vp), ("workspace", fp), ("workspace_floats", i64),
+    ]
+
+
 class ScanClBwdDir(C.Structure):
     _fields_ = [
         ("u", vp), ("xdbl", vp), ("A", fp), ("dt_weight", fp), ("D", fp), ("delta_bias", fp), ("ckpt", fp), ("ypre", vp),
@@ -255,6 +267,8 @@ SYMBOLS = [
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
+    ("cm_conv_cl_bwd_workspace_floats", C.c_int64, [i32, i32, i32]),
+    ("cm_conv_cl_bwd", C.c_int, [C.POINTER(ConvClBwdArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),
     ("cm_add_layernorm", C.c_int, [C.POINTER(AddLnArgs)]),
     ("cm_glu_dwconv_ln_gelu", C.c_int, [C.POINTER(GluDwconvArgs)]),

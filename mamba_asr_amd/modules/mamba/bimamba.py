@@ -166,6 +166,11 @@ class Mamba(nn.Module):
         if inference_params is not None:
             raise NotImplementedError("stateful decoding (reference bimamba.py:184-189, 320-406) is not on the "
                                       "training/encoder path and has no HIP kernel yet")
+        from . import mixer_rows
+        if mixer_rows.supported(self, hidden_states):
+            # the whole mixer as one autograd node on channels-last rows (mixer_rows.py): one scan launch for both directions
+            # in each pass, no (B, E, T) round trip
+            return mixer_rows.mixer_rows(self, hidden_states)
         batch, seqlen, _ = hidden_states.shape
         # in_proj with the (b l d) -> (b d l) transpose folded in (reference :192-198)
         if hidden_states.is_cuda:
@@ -263,6 +268,9 @@ class UniMamba(nn.Module):
     def forward(self, hidden_states, inference_params=None):
         if inference_params is not None:
             raise NotImplementedError("inference_params caches are not used by the ConMamba recipes: call step()")
+        from . import mixer_rows
+        if mixer_rows.supported(self, hidden_states):
+            return mixer_rows.mixer_rows(self, hidden_states)
         batch, seqlen, _ = hidden_states.shape
         xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, -1).t()).reshape(-1, batch, seqlen)
         xz = xz.transpose(0, 1)

@@ -1,0 +1,203 @@
+"""The Mamba mixer of a ConMamba layer as ONE autograd node on channels-last rows — MI355X-first counterpart of the
+reference's MambaInnerFnNoOutProj (modules/mamba/selective_scan_interface.py:160-294) run twice by bimamba.Mamba.forward
+(modules/mamba/bimamba.py:176-253), and of MambaInnerFn (:297-439) for the unidirectional mixer of the Mamba decoder.
+
+Forward and backward stay on the layout the in_proj GEMM writes, (batch * time, channels) rows, end to end:
+
+    forward   xz = hidden W_in^T  ->  cm_conv_xproj (both directions' conv + SiLU and x_proj; cm_conv_cl_fwd + a GEMM where
+              that kernel has no instantiation)  ->  cm_scan_cl_fwd (row-group scan, both directions in one launch; writes the
+              half-block checkpoints and the pre-gate output)  ->  out = [y_f | y_b] [s W_out | s W_out]^T
+    backward  dmix = dY (s W_out)  ->  cm_scan_cl_bwd (both directions: du, dz shares, dx_dbl incl. the dt columns, dA, dD,
+              d dt_proj)  ->  du += dx_dbl W_x, dW_x  ->  cm_conv_cl_bwd (dx of both directions summed, dz summed, conv
+              gradients)  ->  dhidden = dxz W_in, dW_in
+
+against the reference's per-direction (B, E, T) tensors: no flips, no transposes, no `.contiguous()` copies, 1 scan launch
+instead of 2 in each pass, and nothing recomputed but the conv pre-activation (the reference recomputes conv and delta,
+checkpoint_lvl 1, :243-246; here u is kept: 288 GB of HBM).  Numerics: what the operator API computes, with the same bf16
+rounding points under autocast (GEMM operands; delta stays fp32 inside the scan).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch.amp import custom_bwd, custom_fwd
+
+from ... import ops
+
+# CM_ROWS_TRAIN=0: the mixers run on the (B, E, T) operator API (selective_scan_interface._MambaInner) as in rounds 1-2
+ENABLED = os.environ.get("CM_ROWS_TRAIN", "1") == "1"
+
+
+def supported(m, hidden: torch.Tensor) -> bool:
+    """m: bimamba.Mamba (v2) or bimamba.UniMamba."""
+    if not (ENABLED and hidden.is_cuda and hidden.dim() == 3):
+        return False
+    cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden.dtype
+    if cdt not in (torch.float32, torch.bfloat16):
+        return False
+    return (m.d_state == 16 and m.d_conv == 4 and m.d_inner % 8 == 0 and m.in_proj.bias is None and m.out_proj.bias is None
+            and getattr(m, "init_layer_scale", None) is None and (m.dt_rank <= 16 or (m.dt_rank <= 32 and cdt == torch.bfloat16))
+            and m.conv1d.bias is not None)
+
+
+class _Derived:
+    """Per-module operands derived from the parameters, rebuilt when a parameter changes (optimizer step, load_state_dict):
+    compute-dtype copies, x_proj re-rowed to [dt (zero padded to P) | B | C] as cm_scan_cl_fwd reads it, its packed image
+    for cm_conv_xproj, the zero-padded dt_proj weight (rounded to the compute dtype like the reference's GEMM operand,
+    selective_scan_interface.py:187), A = -exp(A_log), the K-concatenated out_proj weight."""
+
+    def __init__(self, m, sfx, cdt, scale):
+        self.key = self.make_key(m, cdt)
+        E, R = m.d_inner, m.dt_rank
+        P = ops.rows_dt_pad(R)
+        self.P, self.RW = P, P + 32
+        self.w_in = m.in_proj.weight.detach().to(cdt)
+        self.w_out = (m.out_proj.weight.detach() * scale).to(cdt)                       # (D, E), scaled
+        self.w_out_cat = torch.cat([self.w_out] * len(sfx), dim=1).contiguous()          # (D, ndir * E)
+        self.xr, self.xr_packed, self.dtw, self.A = [], [], [], []
+        for s in sfx:
+            xp, dtp = getattr(m, "x_proj" + s), getattr(m, "dt_proj" + s)
+            xr = torch.zeros(self.RW, E, dtype=cdt, device=xp.weight.device)
+            xr[:R] = xp.weight.detach()[:R].to(cdt)
+            xr[P:] = xp.weight.detach()[R:].to(cdt)
+            self.xr.append(xr)
+            self.dtw.append(ops.pad_dt_weight(dtp.weight.detach().to(cdt)))
+            self.A.append((-torch.exp(getattr(m, "A_b_log" if s else "A_log").detach().float())).contiguous())
+        if cdt == torch.bfloat16 and len(sfx) == 2 and E % 32 == 0 and E <= 2048:
+            self.xr_packed = [ops.PackedWeight(x) for x in self.xr]
+
+    @staticmethod
+    def make_key(m, cdt):
+        return (cdt,) + tuple((p._version, p.data_ptr()) for p in m.parameters())
+
+
+def _derived(m, sfx, cdt, scale) -> _Derived:
+    d = getattr(m, "_cm_rows_derived", None)
+    if d is None or d.key != _Derived.make_key(m, cdt):
+        d = _Derived(m, sfx, cdt, scale)
+        m._cm_rows_derived = d
+    return d
+
+
+class MixerRowsFn(torch.autograd.Function):
+    """hidden (B, T, D) -> (B, T, D).  Parameters per direction: conv weight (E, 1, 4), conv bias, x_proj weight (R + 32, E),
+    dt_proj weight (E, R), dt_proj bias, A_log (E, 16), D (E); then in_proj weight (2E, D), out_proj weight (D, E)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, hidden, m, sfx, scale, *params):
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden.dtype
+        dv = _derived(m, sfx, cdt, scale)
+        ndir = len(sfx)
+        B, T, D = hidden.shape
+        E, R, P, RW = m.d_inner, m.dt_rank, dv.P, dv.RW
+        dev = hidden.device
+        h2 = hidden.detach().to(cdt)
+        h2 = h2 if h2.is_contiguous() else h2.contiguous()
+        xz = torch.mm(h2.view(B * T, D), dv.w_in.t()).view(B, T, 2 * E)
+        x, z = xz[:, :, :E], xz[:, :, E:]
+        convs = [getattr(m, "conv1d" + s) for s in sfx]
+        cw = [c.weight.detach().float().reshape(E, -1) for c in convs]
+        cb = [c.bias.detach().float() for c in convs]
+        ucat = torch.empty((B, T, ndir * E), dtype=cdt, device=dev)
+        if dv.xr_packed:
+            xdbl = ops.conv_xproj(x, cw[0], cb[0], cw[1], cb[1], dv.xr_packed[0], dv.xr_packed[1], out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+        else:
+            if ndir == 2:
+                ops.conv_cl_fwd(x, cw[0], cb[0], cw[1], cb[1], out_f=ucat[:, :, :E], out_b=ucat[:, :, E:])
+            else:
+                ops.conv_cl_fwd(x, cw[0], cb[0], out_f=ucat)
+            xdbl = torch.empty((B, T, ndir * RW), dtype=cdt, device=dev)
+            for i in range(ndir):
+                xdbl.view(B * T, ndir * RW)[:, RW * i:RW * (i + 1)] = torch.mm(ucat.view(B * T, ndir * E)[:, E * i:E * (i + 1)], dv.xr[i].t())
+        need_grad = any(ctx.needs_input_grad)
+        ycat = torch.empty((B, T, ndir * E), dtype=cdt, device=dev)
+        pcat = torch.empty((B, T, ndir * E), dtype=cdt, device=dev) if need_grad else None
+        cks, dirs = [], []
+        for i, s in enumerate(sfx):
+            dtp = getattr(m, "dt_proj" + s)
+            dd = dict(u=ucat[:, :, E * i:E * (i + 1)], xdbl=xdbl[:, :, RW * i:RW * (i + 1)], A=dv.A[i], D=getattr(m, "D_b" if s else "D").detach().float(),
+                      delta_bias=dtp.bias.detach().float(), dt_weight=dv.dtw[i], reverse=bool(s), out=ycat[:, :, E * i:E * (i + 1)])
+            if need_grad:
+                ck = torch.empty(ops.scan_ckpt_shape(B, T, E), dtype=torch.float32, device=dev)
+                cks.append(ck)
+                dd.update(ypre=pcat[:, :, E * i:E * (i + 1)], ckpt=ck)
+            dirs.append(dd)
+        ops.scan_cl_fwd(dirs, z=z, delta_softplus=True)
+        out = torch.mm(ycat.view(B * T, ndir * E), dv.w_out_cat.t()).view(B, T, D)
+        if need_grad:
+            ctx.m, ctx.sfx, ctx.scale, ctx.dv, ctx.cdt = m, sfx, scale, dv, cdt
+            ctx.save_for_backward(h2, xz, ucat, xdbl, pcat, ycat, *cks)
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dY):
+        m, sfx, scale, dv, cdt = ctx.m, ctx.sfx, ctx.scale, ctx.dv, ctx.cdt
+        h2, xz, ucat, xdbl, pcat, ycat, *cks = ctx.saved_tensors
+        ndir = len(sfx)
+        B, T, D = h2.shape
+        E, R, P, RW = m.d_inner, m.dt_rank, dv.P, dv.RW
+        dev = h2.device
+        dY = dY.to(cdt)
+        dY = dY if dY.is_contiguous() else dY.contiguous()
+        x, z = xz[:, :, :E], xz[:, :, E:]
+        # out_proj: every direction sees the same gradient, dmix = dY (scale W_out)
+        dmix = torch.mm(dY.view(B * T, D), dv.w_out).view(B, T, E)
+        d_out_cat = torch.bmm(dY.transpose(1, 2), ycat).sum(0)                          # (D, ndir * E): per utterance, then summed
+        d_out_w = d_out_cat[:, :E] if ndir == 1 else d_out_cat[:, :E] + d_out_cat[:, E:]
+        d_out_w = d_out_w * scale
+        # scan backward, all directions in one launch
+        ducat = torch.empty((B, T, ndir * E), dtype=cdt, device=dev)
+        dxdbl = torch.empty((B, T, ndir * RW), dtype=cdt, device=dev)
+        dxz = torch.empty((B, T, 2 * E), dtype=cdt, device=dev)
+        dzs = [dxz[:, :, E:]] if ndir == 1 else [torch.empty((B, T, E), dtype=cdt, device=dev) for _ in range(ndir)]
+        dirs = []
+        for i, s in enumerate(sfx):
+            dtp = getattr(m, "dt_proj" + s)
+            dirs.append(dict(u=ucat[:, :, E * i:E * (i + 1)], xdbl=xdbl[:, :, RW * i:RW * (i + 1)], A=dv.A[i],
+                             D=getattr(m, "D_b" if s else "D").detach().float(), delta_bias=dtp.bias.detach().float(), dt_weight=dv.dtw[i],
+                             reverse=bool(s), ckpt=cks[i], ypre=pcat[:, :, E * i:E * (i + 1)], dout=dmix, du=ducat[:, :, E * i:E * (i + 1)], dz=dzs[i],
+                             dxdbl=dxdbl[:, :, RW * i:RW * (i + 1)]))
+        res = ops.scan_cl_bwd(dirs, z)
+        # x_proj: weight gradient per utterance + sum (K = batch * time GEMMs with a 48-row output fill few workgroups), input
+        # gradient added to du in place
+        grads = []
+        du2, dx2 = ducat.view(B * T, ndir * E), dxdbl.view(B * T, ndir * RW)
+        dxr = []
+        for i in range(ndir):
+            dxr.append(torch.bmm(dxdbl[:, :, RW * i:RW * (i + 1)].transpose(1, 2), ucat[:, :, E * i:E * (i + 1)]).sum(0))     # (RW, E)
+            du2[:, E * i:E * (i + 1)].addmm_(dx2[:, RW * i:RW * (i + 1)], dv.xr[i])
+        convs = [getattr(m, "conv1d" + s) for s in sfx]
+        cw = [c.weight.detach().float().reshape(E, -1) for c in convs]
+        cb = [c.bias.detach().float() for c in convs]
+        if ndir == 2:
+            _, _, dwf, dbf, dwb, dbb = ops.conv_cl_bwd(x, cw[0], cb[0], ducat[:, :, :E], cw[1], cb[1], ducat[:, :, E:], dz_f=dzs[0], dz_b=dzs[1],
+                                                       dx=dxz[:, :, :E], dz=dxz[:, :, E:])
+            dconv = [(dwf, dbf), (dwb, dbb)]
+        else:
+            _, _, dwf, dbf, _, _ = ops.conv_cl_bwd(x, cw[0], cb[0], ducat, dx=dxz[:, :, :E])
+            dconv = [(dwf, dbf)]
+        d_hidden = torch.mm(dxz.view(B * T, 2 * E), dv.w_in).view(B, T, D) if ctx.needs_input_grad[0] else None
+        d_in_w = torch.bmm(dxz.transpose(1, 2), h2).sum(0)                              # (2E, D)
+        for i, s in enumerate(sfx):
+            r = res[i]
+            dxw = torch.cat([dxr[i][:R], dxr[i][P:]], dim=0)                            # back to x_proj's (R + 32, E) rows
+            grads += [dconv[i][0].reshape(convs[i].weight.shape), dconv[i][1], dxw, r["ddt_weight"][:, :R], r["ddelta_bias"],
+                      r["dA"] * dv.A[i], r["dD"]]
+        grads += [d_in_w, d_out_w]
+        return (d_hidden, None, None, None, *grads)
+
+
+def mixer_rows(m, hidden):
+    """Run module ``m`` (bimamba.Mamba v2 or bimamba.UniMamba) on the rows node; caller checked ``supported``."""
+    bidir = hasattr(m, "A_b_log")
+    sfx = ("", "_b") if bidir else ("",)
+    scale = 0.5 if (bidir and m.if_devide_out) else 1.0
+    params = []
+    for s in sfx:
+        conv, xp, dtp = getattr(m, "conv1d" + s), getattr(m, "x_proj" + s), getattr(m, "dt_proj" + s)
+        params += [conv.weight, conv.bias, xp.weight, dtp.weight, dtp.bias, getattr(m, "A_b_log" if s else "A_log"), getattr(m, "D_b" if s else "D")]
+    params += [m.in_proj.weight, m.out_proj.weight]
+    return MixerRowsFn.apply(hidden, m, sfx, scale, *params)

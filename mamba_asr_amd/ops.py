@@ -442,6 +442,49 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split
     return outs
 
 
+def conv_cl_bwd(x, weight_f, bias_f, du_f, weight_b=None, bias_b=None, du_b=None, dz_f=None, dz_b=None, dx=None, dz=None):
+    """Backward of the channels-last causal depthwise conv + SiLU, one or both BiMamba directions in one pass
+    (cm_conv_cl_bwd).  x, du_*, dz_* (batch, seqlen, dim) views; weights (dim, 4).  dx = dx_fwd + dx_bwd; dz = dz_f + dz_b
+    when given.  Returns (dx, dz or None, dweight_f, dbias_f, dweight_b, dbias_b) with fp32 parameter gradients."""
+    _dev_check(x, weight_f, bias_f, du_f, weight_b, bias_b, du_b, dz_f, dz_b, dx, dz)
+    for t, nm in ((x, "x"), (du_f, "du_f"), (du_b, "du_b"), (dz_f, "dz_f"), (dz_b, "dz_b"), (dx, "dx"), (dz, "dz")):
+        if t is not None:
+            _rows_ok(t, nm)
+            if t.shape != x.shape or t.dtype != x.dtype:
+                raise RuntimeError(f"conv_cl_bwd: {nm} must match x in shape and dtype")
+    b, l, d = x.shape
+    two = du_b is not None
+    wf, bf, wb, bb = _f32c(weight_f).reshape(d, -1), _f32c(bias_f), (_f32c(weight_b).reshape(d, -1) if two else None), (_f32c(bias_b) if two else None)
+    if dx is None:
+        dx = torch.empty((b, l, d), dtype=x.dtype, device=x.device)
+    if dz is None and dz_f is not None:
+        dz = torch.empty((b, l, d), dtype=x.dtype, device=x.device)
+    dev = x.device
+    dwf, dbf = torch.zeros_like(wf), (torch.zeros((d,), dtype=torch.float32, device=dev) if bf is not None else None)
+    dwb = torch.zeros_like(wb) if two else None
+    dbb = torch.zeros((d,), dtype=torch.float32, device=dev) if (two and bb is not None) else None
+    a = N.ConvClBwdArgs()
+    a.batch, a.seqlen, a.dim, a.width, a.io_dtype = b, l, d, wf.shape[1], _DT[x.dtype]
+    a.x, a.weight_f, a.bias_f, a.weight_b, a.bias_b = _ptr(x), _ptr(wf), _ptr(bf), _ptr(wb), _ptr(bb)
+    a.du_f, a.du_b, a.dz_f, a.dz_b, a.dx, a.dz = _ptr(du_f), _ptr(du_b), _ptr(dz_f), _ptr(dz_b), _ptr(dx), _ptr(dz)
+    a.dweight_f, a.dbias_f, a.dweight_b, a.dbias_b = _ptr(dwf), _ptr(dbf), _ptr(dwb), _ptr(dbb)
+    a.x_bs, a.x_ts, a.duf_bs, a.duf_ts = x.stride(0), x.stride(1), du_f.stride(0), du_f.stride(1)
+    if two:
+        a.dub_bs, a.dub_ts = du_b.stride(0), du_b.stride(1)
+    if dz_f is not None:
+        a.dzf_bs, a.dzf_ts = dz_f.stride(0), dz_f.stride(1)
+    if dz_b is not None:
+        a.dzb_bs, a.dzb_ts = dz_b.stride(0), dz_b.stride(1)
+    a.dx_bs, a.dx_ts = dx.stride(0), dx.stride(1)
+    if dz is not None:
+        a.dz_bs, a.dz_ts = dz.stride(0), dz.stride(1)
+    nws = int(N.lib().cm_conv_cl_bwd_workspace_floats(b, l, d))
+    ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+    a.workspace, a.workspace_floats, a.stream = _ptr(ws), nws, _stream()
+    _launch("cm_conv_cl_bwd", N.lib().cm_conv_cl_bwd, a, units=b * l)
+    return dx, dz, dwf, dbf, dwb, dbb
+
+
 def scan_ckpt_shape(batch: int, seqlen: int, dim: int):
     """Shape of the checkpoint tensor the training forward writes (cm_scan_cl_dir.ckpt)."""
     return (batch, 2 * ((seqlen + 15) // 16), dim, 16)

@@ -109,7 +109,8 @@ def test_training_step_loss_and_every_gradient_vs_oracle():
     cfg, model, wavs, lens, tokens, tok_lens = _train_case()
     ref_loss, ref = _oracle_loss_and_grads(cfg, model, wavs, lens, tokens, tok_lens, 2)
     loss, grads, names = _gpu_loss_and_grads(model, wavs, lens, tokens, tok_lens)
-    for k in ("cm_selective_scan_fwd", "cm_selective_scan_bwd", "cm_causal_conv1d_bwd", "cm_layernorm_bwd", "cm_dwconv_cl_bwd"):
+    # the mixers run as the channels-last rows node (modules/mamba/mixer_rows.py): row-group scan forward / backward, both directions per launch
+    for k in ("cm_scan_cl_fwd", "cm_scan_cl_bwd", "cm_conv_cl_bwd", "cm_layernorm_bwd", "cm_dwconv_cl_bwd"):
         assert k in names, f"{k} did not run in the training step (ran: {sorted(names)})"
     d = abs(float(loss) - float(ref_loss))
     print(f"training step, fp32: CTC oracle(fp64) {float(ref_loss):.6f} gpu {float(loss):.6f} |delta| {d:.2e}")
@@ -135,14 +136,15 @@ def test_training_step_loss_and_every_gradient_vs_oracle():
     assert not bad, bad
 
 
-def _same_grads(a, b, names):
+def _same_grads(a, b, names, cnn_tol=1e-5):
     """Bit-equal outside the CNN front end; the front end's conv2d backward is the vendor library's (MIOpen weight / data
-    gradient kernels accumulate with atomics: last-bit differences from run to run) -- its four tensors within 1e-5 of
-    their scale.  The encoder, the src Linear and the CTC head run on this package's deterministic kernels."""
+    gradient kernels accumulate with atomics: last-bit differences from run to run -- last bf16 bits under autocast) -- its
+    tensors within cnn_tol of their scale.  The encoder, the src Linear and the CTC head run on this package's deterministic
+    kernels."""
     ok = True
     for k, x, y in zip(names, a, b):
         if k.startswith("CNN."):
-            ok = ok and float((x - y).abs().max()) <= 1e-5 * float(y.abs().max().clamp_min(1e-30))
+            ok = ok and float((x - y).abs().max()) <= cnn_tol * float(y.abs().max().clamp_min(1e-30))
         else:
             ok = ok and torch.equal(x, y)
     return ok
@@ -210,10 +212,11 @@ for autocast in (False, True):
             torch.cuda.synchronize()
             key = f"{'bf16' if autocast else 'fp32'}-{algo}-{'bf16' if cdt else 'fp32'}"
             got = [p.grad for p in params]
-            if cdt is None:                            # (the CNN front end's vendor conv backward: see _same_grads)
-                out[key] = _same_grads(got, plain, names)
+            tol = 3e-2 if (autocast or cdt is not None) else 1e-5     # the CNN front end's vendor conv backward: see _same_grads
+            if cdt is None:
+                out[key] = _same_grads(got, plain, names, tol)
             else:                                      # bf16 transport: the gradient rounded to bf16 once
-                out[key] = _same_grads([x.bfloat16().float() for x in got], [q.bfloat16().float() for q in plain], names)
+                out[key] = _same_grads([x.bfloat16().float() for x in got], [q.bfloat16().float() for q in plain], names, tol)
             out[key + "-views"] = all(p.grad.data_ptr() == red._view[p].data_ptr() for p in params)
             out[key + "-bytes"] = red.bytes_per_step()
             red.close()                                # remove this reducer's hooks before the next one registers its own

@@ -109,3 +109,44 @@ def test_scan_rows_fwd_training_outputs():
                        dt_weight=dd["dt_weight"], reverse=rev, h_last=hl)
             ops.scan_cl_fwd([sub], z=gz[:, lo:hi], delta_softplus=True, time_chunks=1)
             torch.testing.assert_close(ck[:, m], hl, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 64), (1, 130, 200), (3, 64, 72), (2, 300, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("two", [True, False])
+def test_conv_cl_bwd(shape, dtype, two):
+    """cm_conv_cl_bwd vs the oracle's causal-conv backward per direction (oracle.causal_conv1d_bwd, pinned by k_conv.npz);
+    the reverse direction through flipped tensors as the reference does it (bimamba.py:237)."""
+    from mamba_asr_amd import ops
+    b, l, e = shape
+    gen = torch.Generator().manual_seed(l + e)
+    xz = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    x = xz[:, :, :e]
+    du = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    dzs = torch.randn(b, l, 2 * e, generator=gen).to(dtype)
+    w = [torch.randn(e, 4, generator=gen) * 0.5 for _ in range(2)]
+    bs = [torch.randn(e, generator=gen) * 0.2 for _ in range(2)]
+    gxz, gdu, gdz = xz.to(DEV), du.to(DEV), dzs.to(DEV)
+    dxz = torch.zeros(b, l, 2 * e, dtype=dtype, device=DEV)
+    args = dict(du_b=gdu[:, :, e:], weight_b=w[1].to(DEV), bias_b=bs[1].to(DEV), dz_b=gdz[:, :, e:]) if two else {}
+    dx, dz, dwf, dbf, dwb, dbb = ops.conv_cl_bwd(gxz[:, :, :e], w[0].to(DEV), bs[0].to(DEV), gdu[:, :, :e], dz_f=gdz[:, :, :e],
+                                                 dx=dxz[:, :, :e], dz=dxz[:, :, e:], **args)
+    tr = lambda t: t.double().transpose(1, 2)
+    rdx, rdw, rdb = O.causal_conv1d_bwd(tr(x), w[0], bs[0], tr(du[:, :, :e]), True)
+    want_dx, want_dz = rdx, dzs[:, :, :e].double()
+    f32 = dtype == torch.float32
+    rt, at = (2e-4, 2e-5) if f32 else (1.6e-2, 1e-2)
+    if two:
+        bdx, bdw, bdb = O.causal_conv1d_bwd(tr(x).flip(-1), w[1], bs[1], tr(du[:, :, e:]).flip(-1), True)
+        want_dx = want_dx + bdx.flip(-1)
+        want_dz = want_dz + dzs[:, :, e:].double()
+        close(dwb, bdw, 1e-3 if f32 else 1e-2, 1e-4 if f32 else 2e-3)
+        close(dbb, bdb, 1e-3 if f32 else 1e-2, 1e-4 if f32 else 2e-3)
+    else:
+        assert dwb is None and dbb is None
+    close(dxz[:, :, :e].float(), want_dx.transpose(1, 2), rt, at)
+    close(dxz[:, :, e:].float(), want_dz, rt, at)
+    close(dwf, rdw, 1e-3 if f32 else 1e-2, 1e-4 if f32 else 2e-3)
+    close(dbf, rdb, 1e-3 if f32 else 1e-2, 1e-4 if f32 else 2e-3)
+    again = ops.conv_cl_bwd(gxz[:, :, :e], w[0].to(DEV), bs[0].to(DEV), gdu[:, :, :e], dz_f=gdz[:, :, :e], **args)
+    assert torch.equal(again[0], dxz[:, :, :e]) and torch.equal(again[2], dwf) and torch.equal(again[3], dbf)
