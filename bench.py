@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=4000, help="10 ms audio frames per utterance (L)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="forward mode, 1 GPU: skip the extra keys of the line (\"train\": the training micro-batch of --mode train at 32 utterances; "
+                         "\"survey_b16\": the forward at SURVEY §8d's 16 x 40 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 2)")
     ap.add_argument("--stream-mode", choices=["join", "free"], default=None,
@@ -141,7 +144,7 @@ def make_batch(a, cfg, rank, dev):
     return wavs, lens
 
 
-def run_train(a, cfg, dev, rank, world, use_dist):
+def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
     """Data-parallel training step (BASELINE.json config 4; reference train_CTC.py fit_batch through speechbrain's Brain +
     DDP, hparams/CTC/conmamba_large.yaml:84-91, 243-252): bf16 autocast, SpecAugment, CTC loss, backward, and every
     ``--accum``-th micro-batch the gradient exchange (mamba_asr_amd.ddp over RCCL), clip 5.0, AdamW, Noam.
@@ -225,16 +228,23 @@ def run_train(a, cfg, dev, rank, world, use_dist):
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
     if rank == 0:
-        ts = [e0.elapsed_time(e1) for name, e0, e1, _ in log if name == "cm_selective_scan_bwd"]
-        if ts:
-            e_inner, n_state, s_ = cfg.expand * cfg.d_model, cfg.d_state, (2 if a.dtype == "bf16" else 4)
-            units = a.batch * (a.frames // 4)                                       # scan steps per launch (one direction)
-            alg = units * (9 * e_inner + 4 * n_state) * s_                          # fwd reads + dout, du/ddelta/dz + dB/dC
+        e_inner, n_state, s_ = cfg.expand * cfg.d_model, cfg.d_state, (2 if a.dtype == "bf16" else 4)
+        per_step = (9 * e_inner + 4 * n_state) * s_                                 # fwd reads + dout, du / ddelta / dz + dB / dC, per scan step and direction
+        for name, label, ndir in (("cm_scan_cl_bwd", "scan_rows_bwd_kernel + fixed-order reduce (cm_scan_cl_bwd: both BiMamba directions per launch)", 2),
+                                  ("cm_selective_scan_bwd", "scan_bwd_kernel (cm_selective_scan_bwd, one direction per launch)", 1)):
+            # encoder launches only (a decoder's scans have other sizes): the most frequent unit count
+            ts_all = [(e0.elapsed_time(e1), u) for nm, e0, e1, u in log if nm == name]
+            if not ts_all:
+                continue
+            u_enc = a.batch * (a.frames // 4) * ndir
+            ts = [t for t, u in ts_all if u == u_enc] or [t for t, _ in ts_all]
+            alg = u_enc * per_step
             avg_ms = sum(ts) / len(ts)
             roof = {"bound": "hbm", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "scan_bwd_kernel (cm_selective_scan_bwd, one direction per launch)",
-                    "avg_launch_us": round(avg_ms * 1e3, 1), "launches_per_step": len(ts), "alg_bytes_per_launch": alg}
+                    "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": label,
+                    "avg_launch_us": round(avg_ms * 1e3, 1), "us_per_direction": round(avg_ms * 1e3 / ndir, 1),
+                    "launches_per_step": len(ts), "alg_bytes_per_launch": alg}
+            break
     if rank == 0:
         line = {"metric": f"training audio-frames/sec ({cfg.name}, L={a.frames}, fwd+bwd+AdamW" + (", encoder + Mamba decoder, 0.3 CTC + 0.7 KL)" if s2s else ")"),
                 "value": round(value, 1),
@@ -250,7 +260,10 @@ def run_train(a, cfg, dev, rank, world, use_dist):
                 "exposed_comm_ms_per_optimizer_step": round(1e3 * sum(exposed) / len(exposed), 3) if exposed else None,
                 "optimizer_steps": brain.optimizer_step, "loss_first_last": [round(losses[0], 3), round(losses[-1], 3)],
                 "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "roofline": roof, "cpu_baseline": None}
-        emit(line)
+        if emit_line:
+            emit(line)
+        return line
+    return None
 
 
 _result_fd = None
@@ -400,9 +413,51 @@ def main():
                     "event_interval_us": round(raw_ms * 1e3, 1), "event_pair_overhead_us": round(pair_overhead_ms * 1e3, 1),
                     "launches_per_step": len(scans) // 3, "alg_bytes_per_launch": alg_bytes}
 
+    # ---- extra keys (1 GPU, the default configuration): SURVEY §8d's 16 x 40 s forward, and the training micro-batch
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras and a.config == "conmamba_large_ctc" and a.batch != 16 and not a.no_graph:
+        import copy
+        a16 = copy.copy(a)
+        a16.batch = 16
+        w16, l16 = make_batch(a16, cfg, rank, dev)
+        g16 = GraphedEncode(model, w16, l16, dtype=torch.bfloat16 if amp is not None else torch.float32)
+        for _ in range(3):
+            g16()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            g16()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ops.LAUNCH_LOG = []
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp is not None):
+            for _ in range(2):
+                model.encode(w16, l16)
+        torch.cuda.synchronize()
+        log16, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        sc = [e0.elapsed_time(e1) for nm, e0, e1, _ in log16 if nm == "cm_scan_cl_fwd"]
+        sc = sc[len(sc) // 2:]                                                       # the second pass
+        s_ = 2 if amp is not None else 4
+        alg16 = 16 * (a.frames // 4) * 2 * (4 * cfg.expand * cfg.d_model + 2 * cfg.d_state) * s_
+        extras["survey_b16"] = {"workload": f"16 utterances x {a.frames} frames (SURVEY §8d's batch)", "value": round(16 * a.frames * a.steps / el, 1),
+                                "ms_per_step": round(el / a.steps * 1e3, 3),
+                                "scan_event_interval_us": round(sum(sc) / len(sc) * 1e3, 1) if sc else None,
+                                "scan_roofline_frac_raw_interval": round(alg16 / (sum(sc) / len(sc) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None}
+        del g16, w16, l16
     base = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         base = cpu_baseline(model, cfg, a.cpu_frames, a.cpu_batch)
+    if rank == 0 and world == 1 and not a.no_extras and a.config == "conmamba_large_ctc":
+        import copy
+        at = copy.copy(a)
+        at.batch, at.steps, at.warmup, at.accum, at.comm_dtype, at.ddp_algo = 32, 8, 4, 4, "f32", None
+        graphed = step = out = None                                                  # release the forward's graph and buffers
+        del model
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        tl = run_train(at, cfg, dev, rank, world, False, emit_line=False)
+        extras["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "peak_mem_gib", "optimizer_steps", "roofline")}
+        extras["train"]["workload"] = tl["config"]["workload"]
 
     if rank == 0:
         # whole-path roofline position (SURVEY §8d canonical bytes per audio frame, bf16)
@@ -424,6 +479,7 @@ def main():
             "path_hbm_frac": None if bytes_per_frame is None else round(value / world * bytes_per_frame / 8e12, 4),
             "roofline": roof, "cpu_baseline": base,
         }
+        line.update(extras)
         emit(line)
     if use_dist:
         dist.destroy_process_group()

@@ -358,6 +358,11 @@ typedef struct cm_conv_cl_bwd_args {
     int64_t workspace_floats;
 } cm_conv_cl_bwd_args;
 
+/* out[j] = sum over b < nbatch of in[b * n + j], fp32 accumulation in a fixed order: folds the per-utterance weight-gradient
+ * products of the training step (the reference forms them as one K = batch * time GEMM inside autograd).  in / out dtype:
+ * CM_F32 or CM_BF16; n a multiple of 8 (bf16 in) / 4 (fp32 in); 16-byte aligned. */
+int cm_sum_leading(const void *in, void *out, int32_t nbatch, int64_t n, int32_t in_dtype, int32_t out_dtype, void *stream);
+
 int64_t cm_conv_cl_bwd_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);
 int cm_conv_cl_bwd(const cm_conv_cl_bwd_args *args);
 

@@ -267,6 +267,7 @@ SYMBOLS = [
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
+    ("cm_sum_leading", C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
     ("cm_conv_cl_bwd_workspace_floats", C.c_int64, [i32, i32, i32]),
     ("cm_conv_cl_bwd", C.c_int, [C.POINTER(ConvClBwdArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),

@@ -138,13 +138,23 @@ __global__ __launch_bounds__(256) void conv_cl_bwd_kernel(const cm_conv_cl_bwd_a
         for (int s = 0; s < NSLOT; ++s) ws[j * NSLOT + s] = acc[j][s];
 }
 
-// fixed-order sum over (batch, time group), ACCUMULATED into the caller's fp32 gradients
+// fixed-order sum over (batch, time group), ACCUMULATED into the caller's fp32 gradients: 32 columns x 8 row groups per workgroup
 __global__ __launch_bounds__(256) void conv_cl_bwd_reduce_kernel(const cm_conv_cl_bwd_args p, const int ngroup) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.dim * NSLOT) return;
-    float a = 0.f;
+    __shared__ float red[8][32];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    const int ncol = p.dim * NSLOT;
     const int64_t n = (int64_t)p.batch * ngroup;
-    for (int64_t r = 0; r < n; ++r) a += p.workspace[r * p.dim * NSLOT + i];
+    float part = 0.f;
+    if (i < ncol) {
+#pragma unroll 8
+        for (int64_t r = rg; r < n; r += 8) part += p.workspace[r * ncol + i];
+    }
+    red[rg][threadIdx.x & 31] = part;
+    __syncthreads();
+    if (rg != 0 || i >= ncol) return;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][threadIdx.x & 31];
     const int c = i / NSLOT, s = i % NSLOT;
     if (s < W) p.dweight_f[c * W + s] += a;
     else if (s == W) { if (p.dbias_f) p.dbias_f[c] += a; }
@@ -192,6 +202,6 @@ extern "C" int cm_conv_cl_bwd(const cm_conv_cl_bwd_args *args) {
         else hipLaunchKernelGGL((conv_cl_bwd_kernel<float, false>), grid, dim3(256), 0, st, a, vpr, ngroup);
     }
     if (int rc = cm_launch_status("cm_conv_cl_bwd")) return rc;
-    hipLaunchKernelGGL(conv_cl_bwd_reduce_kernel, dim3((unsigned)((a.dim * NSLOT + 255) / 256)), dim3(256), 0, st, a, ngroup);
+    hipLaunchKernelGGL(conv_cl_bwd_reduce_kernel, dim3((unsigned)((a.dim * NSLOT + 31) / 32)), dim3(256), 0, st, a, ngroup);
     return cm_launch_status("cm_conv_cl_bwd(reduce)");
 }

@@ -145,7 +145,7 @@ class MixerRowsFn(torch.autograd.Function):
         x, z = xz[:, :, :E], xz[:, :, E:]
         # out_proj: every direction sees the same gradient, dmix = dY (scale W_out)
         dmix = torch.mm(dY.view(B * T, D), dv.w_out).view(B, T, E)
-        d_out_cat = torch.bmm(dY.transpose(1, 2), ycat).sum(0)                          # (D, ndir * E): per utterance, then summed
+        d_out_cat = ops.sum_leading(torch.bmm(dY.transpose(1, 2), ycat))               # (D, ndir * E): per utterance, then summed (fp32)
         d_out_w = d_out_cat[:, :E] if ndir == 1 else d_out_cat[:, :E] + d_out_cat[:, E:]
         d_out_w = d_out_w * scale
         # scan backward, all directions in one launch
@@ -167,7 +167,7 @@ class MixerRowsFn(torch.autograd.Function):
         du2, dx2 = ducat.view(B * T, ndir * E), dxdbl.view(B * T, ndir * RW)
         dxr = []
         for i in range(ndir):
-            dxr.append(torch.bmm(dxdbl[:, :, RW * i:RW * (i + 1)].transpose(1, 2), ucat[:, :, E * i:E * (i + 1)]).sum(0))     # (RW, E)
+            dxr.append(ops.sum_leading(torch.bmm(dxdbl[:, :, RW * i:RW * (i + 1)].transpose(1, 2), ucat[:, :, E * i:E * (i + 1)])))   # (RW, E)
             du2[:, E * i:E * (i + 1)].addmm_(dx2[:, RW * i:RW * (i + 1)], dv.xr[i])
         convs = [getattr(m, "conv1d" + s) for s in sfx]
         cw = [c.weight.detach().float().reshape(E, -1) for c in convs]
@@ -180,7 +180,7 @@ class MixerRowsFn(torch.autograd.Function):
             _, _, dwf, dbf, _, _ = ops.conv_cl_bwd(x, cw[0], cb[0], ducat, dx=dxz[:, :, :E])
             dconv = [(dwf, dbf)]
         d_hidden = torch.mm(dxz.view(B * T, 2 * E), dv.w_in).view(B, T, D) if ctx.needs_input_grad[0] else None
-        d_in_w = torch.bmm(dxz.transpose(1, 2), h2).sum(0)                              # (2E, D)
+        d_in_w = ops.sum_leading(torch.bmm(dxz.transpose(1, 2), h2))                   # (2E, D)
         for i, s in enumerate(sfx):
             r = res[i]
             dxw = torch.cat([dxr[i][:R], dxr[i][P:]], dim=0)                            # back to x_proj's (R + 32, E) rows

@@ -442,6 +442,19 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split
     return outs
 
 
+def sum_leading(t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """t (batch, ...) -> sum over the leading axis with fp32 accumulation in a fixed order (cm_sum_leading): folds per-utterance
+    weight-gradient products; output in ``out_dtype`` (fp32 = a parameter's gradient dtype, no cast afterwards)."""
+    _dev_check(t)
+    n = t[0].numel()
+    vec = 8 if t.dtype == torch.bfloat16 else 4
+    if t.dtype not in (torch.float32, torch.bfloat16) or n % vec or not t.is_contiguous():
+        return t.sum(0).to(out_dtype)
+    out = torch.empty(t.shape[1:], dtype=out_dtype, device=t.device)
+    N.check(N.lib().cm_sum_leading(_ptr(t), _ptr(out), t.shape[0], n, _DT[t.dtype], _DT[out_dtype], _stream()), "cm_sum_leading")
+    return out
+
+
 def conv_cl_bwd(x, weight_f, bias_f, du_f, weight_b=None, bias_b=None, du_b=None, dz_f=None, dz_b=None, dx=None, dz=None):
     """Backward of the channels-last causal depthwise conv + SiLU, one or both BiMamba directions in one pass
     (cm_conv_cl_bwd).  x, du_*, dz_* (batch, seqlen, dim) views; weights (dim, 4).  dx = dx_fwd + dx_bwd; dz = dz_f + dz_b
@@ -460,13 +473,18 @@ def conv_cl_bwd(x, weight_f, bias_f, du_f, weight_b=None, bias_b=None, du_b=None
     if dz is None and dz_f is not None:
         dz = torch.empty((b, l, d), dtype=x.dtype, device=x.device)
     dev = x.device
-    dwf, dbf = torch.zeros_like(wf), (torch.zeros((d,), dtype=torch.float32, device=dev) if bf is not None else None)
-    dwb = torch.zeros_like(wb) if two else None
-    dbb = torch.zeros((d,), dtype=torch.float32, device=dev) if (two and bb is not None) else None
+    kw = wf.shape[1]
     a = N.ConvClBwdArgs()
     a.batch, a.seqlen, a.dim, a.width, a.io_dtype = b, l, d, wf.shape[1], _DT[x.dtype]
     a.x, a.weight_f, a.bias_f, a.weight_b, a.bias_b = _ptr(x), _ptr(wf), _ptr(bf), _ptr(wb), _ptr(bb)
     a.du_f, a.du_b, a.dz_f, a.dz_b, a.dx, a.dz = _ptr(du_f), _ptr(du_b), _ptr(dz_f), _ptr(dz_b), _ptr(dx), _ptr(dz)
+    # the kernel writes contiguous (dim, 4) / (dim) tensors: hand it contiguous staging slices of one zeroed buffer
+    flat = torch.zeros((2 * d * (kw + 1),), dtype=torch.float32, device=dev)
+    dwf, dwb_ = flat[:d * kw].view(d, kw), flat[d * kw:2 * d * kw].view(d, kw)
+    dbf_, dbb_ = flat[2 * d * kw:2 * d * kw + d], flat[2 * d * kw + d:]
+    dbf = dbf_ if bf is not None else None
+    dwb = dwb_ if two else None
+    dbb = dbb_ if (two and bb is not None) else None
     a.dweight_f, a.dbias_f, a.dweight_b, a.dbias_b = _ptr(dwf), _ptr(dbf), _ptr(dwb), _ptr(dbb)
     a.x_bs, a.x_ts, a.duf_bs, a.duf_ts = x.stride(0), x.stride(1), du_f.stride(0), du_f.stride(1)
     if two:
@@ -531,10 +549,13 @@ def scan_cl_bwd(directions, z):
         dx = dd.get("dxdbl") if dd.get("dxdbl") is not None else torch.empty((b, l, pad + 32), dtype=u.dtype, device=u.device)
         for t, nm in ((du, "du"), (dz, "dz"), (dx, "dxdbl")):
             _rows_ok(t, nm)
-        dA = torch.zeros((d, 16), dtype=torch.float32, device=u.device)
-        dW = torch.zeros((d, pad), dtype=torch.float32, device=u.device)
-        dD = torch.zeros((d,), dtype=torch.float32, device=u.device) if D is not None else None
-        db = torch.zeros((d,), dtype=torch.float32, device=u.device) if bias is not None else None
+        if i == 0:                                            # one memset for every accumulated-into gradient of the launch
+            npar = d * (16 + pad + 2)
+            zeros = torch.zeros((len(directions) * npar,), dtype=torch.float32, device=u.device)
+        zp = zeros[i * npar:(i + 1) * npar]
+        dA, dW = zp[:16 * d].view(d, 16), zp[16 * d:(16 + pad) * d].view(d, pad)
+        dD = zp[(16 + pad) * d:(17 + pad) * d] if D is not None else None
+        db = zp[(17 + pad) * d:] if bias is not None else None
         keep += [A, D, bias, dt_w]
         x = a.dir[i]
         x.u, x.xdbl, x.A, x.dt_weight, x.D, x.delta_bias, x.ckpt, x.ypre, x.dout = (_ptr(u), _ptr(xdbl), _ptr(A), _ptr(dt_w), _ptr(D),

@@ -100,7 +100,8 @@ class _LinearRowsFn(torch.autograd.Function):
             dx = torch.matmul(dy, ops.cast_cached(weight, dy.dtype))
         if ctx.needs_input_grad[1]:
             if x.dim() == 3 and x.shape[0] > 1:
-                dw = torch.bmm(dy.transpose(1, 2), x.to(dy.dtype)).sum(0)
+                from . import ops
+                dw = ops.sum_leading(torch.bmm(dy.transpose(1, 2), x.to(dy.dtype)), weight.dtype if weight.dtype in (torch.float32, torch.bfloat16) else torch.float32)
             else:
                 dw = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]).to(dy.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
