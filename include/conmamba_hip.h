@@ -358,6 +358,33 @@ typedef struct cm_conv_cl_bwd_args {
     int64_t workspace_floats;
 } cm_conv_cl_bwd_args;
 
+/* Element-wise stages of a feed-forward / convolution module's training step on (rows, dim) tensors (csrc/ffn_train.hip; the
+ * reference leaves them to torch: reference modules/Conmamba.py:597-617):
+ *   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))  [I/O dtype]      or, with res:  y = res + alpha * dropout(a + bias)  [fp32]
+ *   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias)  [I/O dtype];  dbias += column sums of da (fixed order)
+ * act: 0 none, 1 GELU (erf form).  mask: one byte per element, NULL = no dropout (eval, or p == 0); the forward draws it from a
+ * counter hash of (seed, element index).  dim: multiple of 8, <= 2048; tensors contiguous, 16-byte aligned. */
+typedef struct cm_ffn_elem_args {
+    int64_t rows;
+    int32_t dim, io_dtype, act, dy_f32;      /* dy_f32: backward's dy is fp32 although io_dtype is bf16 (the residual stream)   */
+    const void  *a;                           /* (rows, dim) I/O dtype: the GEMM output without bias (backward: needed when act)  */
+    const float *bias;                        /* (dim) or NULL                                                                     */
+    const float *res;                         /* forward, optional: (rows, dim) fp32 residual                                      */
+    void        *y;                           /* forward out: I/O dtype, or fp32 with res                                          */
+    uint8_t     *mask;                        /* (rows, dim) bytes or NULL                                                         */
+    const void  *dy;                          /* backward in                                                                       */
+    void        *da;                          /* backward out, I/O dtype                                                           */
+    float       *dbias;                       /* backward, optional: (dim) fp32, ACCUMULATED into                                  */
+    float       *dbias_part;                  /* cm_bias_act_dropout_bwd_workspace_floats(rows, dim) floats, required with dbias   */
+    float p, alpha;
+    uint64_t seed;
+    void *stream;
+} cm_ffn_elem_args;
+
+int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim);
+int cm_bias_act_dropout_fwd(const cm_ffn_elem_args *args);
+int cm_bias_act_dropout_bwd(const cm_ffn_elem_args *args);
+
 /* out[j] = sum over b < nbatch of in[b * n + j], fp32 accumulation in a fixed order: folds the per-utterance weight-gradient
  * products of the training step (the reference forms them as one K = batch * time GEMM inside autograd).  in / out dtype:
  * CM_F32 or CM_BF16; n a multiple of 8 (bf16 in) / 4 (fp32 in); 16-byte aligned. */

@@ -77,6 +77,14 @@ class ScanClArgs(C.Structure):
     ]
 
 
+class FfnElemArgs(C.Structure):
+    _fields_ = [
+        ("rows", i64), ("dim", i32), ("io_dtype", i32), ("act", i32), ("dy_f32", i32),
+        ("a", vp), ("bias", fp), ("res", fp), ("y", vp), ("mask", vp), ("dy", vp), ("da", vp), ("dbias", fp), ("dbias_part", fp),
+        ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp),
+    ]
+
+
 class ConvClBwdArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("width", i32), ("io_dtype", i32), ("pad_", i32),
@@ -268,6 +276,9 @@ SYMBOLS = [
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_sum_leading", C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
+    ("cm_bias_act_dropout_bwd_workspace_floats", C.c_int64, [i64, i32]),
+    ("cm_bias_act_dropout_fwd", C.c_int, [C.POINTER(FfnElemArgs)]),
+    ("cm_bias_act_dropout_bwd", C.c_int, [C.POINTER(FfnElemArgs)]),
     ("cm_conv_cl_bwd_workspace_floats", C.c_int64, [i32, i32, i32]),
     ("cm_conv_cl_bwd", C.c_int, [C.POINTER(ConvClBwdArgs)]),
     ("cm_conv_xproj", C.c_int, [C.POINTER(ConvXprojArgs)]),

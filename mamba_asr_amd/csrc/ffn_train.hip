@@ -1,0 +1,221 @@
+// ffn_train.hip — the element-wise stages of a feed-forward module's TRAINING step on (rows, features) tensors, one kernel per
+// stage and direction (the reference leaves them to torch: Linear -> activation -> Dropout -> Linear -> Dropout -> 0.5 x + residual,
+// reference modules/Conmamba.py:597-617, 638-648: eight element-wise launches forward, ten backward per module and micro-batch):
+//   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))                    (a: GEMM output without bias; act: none | GELU(erf))
+//                             or, with `res`:  y = res + alpha * dropout(a + bias)   (fp32 residual stream)
+//   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias);  dbias = column sums of da, through per-workgroup
+//                             partial rows + a fixed-order second pass (deterministic)
+// Dropout masks are one byte per element, drawn from a counter hash of (seed, element index): any Bernoulli(1 - p) mask is the
+// reference's semantics (torch.nn.Dropout); the host draws the seed from torch's seeded generator.
+#include "cm_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {            // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    const uint32_t h = hash32((uint32_t)idx * 0x9E3779B9u + (uint32_t)seed) ^ hash32((uint32_t)(idx >> 32) + (uint32_t)(seed >> 32) + 0x7F4A7C15u);
+    return hash32(h) >= thresh;                                      // P(keep) = 1 - thresh / 2^32
+}
+// d/dx of 0.5 x erfc(-x / sqrt 2)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = cm_gelu(x) / (x == 0.f ? 1.f : x);            // Phi(x) for x != 0
+    const float phi = 0.3989422804014327f * cm_exp2(-0.5f * CM_LOG2E * x * x);
+    return (x == 0.f ? 0.5f : cdf) + x * phi;
+}
+
+template <typename T> __device__ __forceinline__ void ld_vec(const T *p, float *f);
+template <> __device__ __forceinline__ void ld_vec<cm_bf16>(const cm_bf16 *p, float *f) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    f[0] = cm_bf16_lo(v.x), f[1] = cm_bf16_hi(v.x), f[2] = cm_bf16_lo(v.y), f[3] = cm_bf16_hi(v.y);
+    f[4] = cm_bf16_lo(v.z), f[5] = cm_bf16_hi(v.z), f[6] = cm_bf16_lo(v.w), f[7] = cm_bf16_hi(v.w);
+}
+template <> __device__ __forceinline__ void ld_vec<float>(const float *p, float *f) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void st_vec(T *p, const float *f);
+template <> __device__ __forceinline__ void st_vec<cm_bf16>(cm_bf16 *p, const float *f) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4(cm_pack_bf16(f[0], f[1]), cm_pack_bf16(f[2], f[3]), cm_pack_bf16(f[4], f[5]), cm_pack_bf16(f[6], f[7]));
+}
+template <> __device__ __forceinline__ void st_vec<float>(float *p, const float *f) {
+    *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4 *>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// one thread = 8 consecutive features of one row
+template <typename AT, typename YT>
+__global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const cm_ffn_elem_args p) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int vpr = p.dim / 8;
+    if (v >= p.rows * vpr) return;
+    const int64_t e0 = v * 8;
+    const int c = (int)(v % vpr) * 8;
+    float a[8], y[8];
+    ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
+    const bool drop = p.mask != nullptr;
+    const float scale = drop ? 1.f / (1.f - p.p) : 1.f;
+    const uint32_t thresh = drop ? (uint32_t)fminf(p.p * 4294967296.f, 4294967295.f) : 0u;
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float t = a[k] + (p.bias ? p.bias[c + k] : 0.f);
+        if (p.act == 1) t = cm_gelu(t);
+        bool keep = true;
+        if (drop) {
+            keep = keep_elem(p.seed, e0 + k, thresh);
+            (k < 4 ? mlo : mhi) |= (keep ? 1u : 0u) << (8 * (k & 3));
+        }
+        y[k] = keep ? t * scale : 0.f;
+    }
+    if (drop) *reinterpret_cast<uint2 *>(p.mask + e0) = make_uint2(mlo, mhi);
+    if (p.res) {                                                     // y = res + alpha * dropout(a + bias), fp32 stream
+        float r[8];
+        ld_vec<float>(p.res + e0, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = fmaf(p.alpha, y[k], r[k]);
+    }
+    st_vec<YT>(reinterpret_cast<YT *>(p.y) + e0, y);
+}
+
+// workgroup = RP rows per pass x (dim / 8) threads per row, walking `rows_per_wg` rows; column sums of da in registers -> LDS -> one
+// partial row per workgroup
+template <typename AT, typename DYT>
+__global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_elem_args p, const int rows_per_wg) {
+    __shared__ float red[256 * 8];
+    const int vpr = p.dim / 8, rp = 256 / vpr;                      // threads per row, rows per pass
+    const int tr = threadIdx.x / vpr, tc = threadIdx.x % vpr;
+    const bool live = tr < rp;
+    const int c = tc * 8;
+    const bool drop = p.mask != nullptr;
+    const float scale = p.alpha * (drop ? 1.f / (1.f - p.p) : 1.f);
+    float bs[8], acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = p.bias ? p.bias[live ? c + k : 0] : 0.f, acc[k] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (live) {
+        for (int64_t r = r0 + tr; r < r0 + rows_per_wg && r < p.rows; r += rp) {
+            const int64_t e0 = r * p.dim + c;
+            float dy[8], da[8];
+            ld_vec<DYT>(reinterpret_cast<const DYT *>(p.dy) + e0, dy);
+            uint2 m = make_uint2(0x01010101u, 0x01010101u);
+            if (drop) m = *reinterpret_cast<const uint2 *>(p.mask + e0);
+            float a[8];
+            if (p.act == 1) ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool keep = ((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 1u;
+                float g = keep ? dy[k] * scale : 0.f;
+                if (p.act == 1) g *= gelu_grad(a[k] + bs[k]);
+                da[k] = g;
+            }
+            st_vec<AT>(reinterpret_cast<AT *>(p.da) + e0, da);
+            if (p.dbias_part) {
+                // the bias gradient sums what the GEMMs see: the stored (rounded) da
+                float q[8];
+                if constexpr (sizeof(AT) == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const uint32_t w = cm_pack_bf16(da[k], da[k + 1]);
+                        q[k] = cm_bf16_lo(w), q[k + 1] = cm_bf16_hi(w);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q[k] = da[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += q[k];
+            }
+        }
+    }
+    if (!p.dbias_part) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+    __syncthreads();
+    if (live && tr == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = 0.f;
+            for (int j = 0; j < rp; ++j) s += red[(j * vpr + tc) * 8 + k];
+            p.dbias_part[(int64_t)blockIdx.x * p.dim + c + k] = s;
+        }
+    }
+}
+
+// dbias[c] += sum over the partial rows, fixed order: 32 columns x 8 row groups per workgroup
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ part, const int nrow, const int dim, float *__restrict__ out) {
+    __shared__ float red[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float s = 0.f;
+    if (col < dim) {
+#pragma unroll 8
+        for (int b = grp; b < nrow; b += 8) s += part[(int64_t)b * dim + col];
+    }
+    red[grp][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (grp == 0 && col < dim) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+        out[col] += t;
+    }
+}
+
+constexpr int ROWS_PER_WG = 64;
+
+int check(const cm_ffn_elem_args &a, const char *what) {
+    CM_REQUIRE(a.rows > 0 && a.dim > 0, CM_EINVAL, "%s: bad sizes", what);
+    CM_REQUIRE(a.dim % 8 == 0 && a.dim <= 2048, CM_EUNSUPPORTED, "%s: dim %d must be a multiple of 8, at most 2048", what, a.dim);
+    CM_REQUIRE(a.io_dtype == CM_BF16 || a.io_dtype == CM_F32, CM_EUNSUPPORTED, "%s: io dtype %d unsupported", what, a.io_dtype);
+    CM_REQUIRE(a.act == 0 || a.act == 1, CM_EUNSUPPORTED, "%s: act %d (0 none, 1 GELU)", what, a.act);
+    CM_REQUIRE(!a.mask || (a.p > 0.f && a.p < 1.f && cm_aligned(a.mask, 8)), CM_EINVAL, "%s: mask needs 0 < p < 1 and 8-byte alignment", what);
+    return CM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim) {
+    if (rows <= 0 || dim <= 0) return 0;
+    return ((rows + ROWS_PER_WG - 1) / ROWS_PER_WG) * dim;
+}
+
+extern "C" int cm_bias_act_dropout_fwd(const cm_ffn_elem_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "bias_act_dropout_fwd: args is NULL");
+    const cm_ffn_elem_args &a = *args;
+    if (int rc = check(a, "bias_act_dropout_fwd")) return rc;
+    CM_REQUIRE(a.a && a.y && cm_aligned(a.a, 16) && cm_aligned(a.y, 16) && (!a.res || cm_aligned(a.res, 16)), CM_EALIGN,
+               "bias_act_dropout_fwd: a / y (/ res) must be non-NULL and 16-byte aligned");
+    const int64_t threads = a.rows * (a.dim / 8);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    const bool yf = a.res != nullptr || a.io_dtype == CM_F32;        // the residual form writes the fp32 stream
+    if (a.io_dtype == CM_BF16) {
+        if (yf) hipLaunchKernelGGL((bias_act_dropout_fwd_kernel<cm_bf16, float>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bias_act_dropout_fwd_kernel<cm_bf16, cm_bf16>), grid, dim3(256), 0, st, a);
+    } else hipLaunchKernelGGL((bias_act_dropout_fwd_kernel<float, float>), grid, dim3(256), 0, st, a);
+    return cm_launch_status("cm_bias_act_dropout_fwd");
+}
+
+extern "C" int cm_bias_act_dropout_bwd(const cm_ffn_elem_args *args) {
+    CM_REQUIRE(args != nullptr, CM_EINVAL, "bias_act_dropout_bwd: args is NULL");
+    const cm_ffn_elem_args &a = *args;
+    if (int rc = check(a, "bias_act_dropout_bwd")) return rc;
+    CM_REQUIRE(a.dy && a.da && cm_aligned(a.dy, 16) && cm_aligned(a.da, 16) && (a.act == 0 || (a.a && cm_aligned(a.a, 16))), CM_EALIGN,
+               "bias_act_dropout_bwd: dy / da (/ a with an activation) must be non-NULL and 16-byte aligned");
+    CM_REQUIRE(!a.dbias || a.dbias_part, CM_EINVAL, "bias_act_dropout_bwd: dbias needs the partial-row workspace");
+    const int nwg = (int)((a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
+    hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    const bool dyf = a.dy_f32 != 0 || a.io_dtype == CM_F32;
+    if (a.io_dtype == CM_BF16) {
+        if (dyf) hipLaunchKernelGGL((bias_act_dropout_bwd_kernel<cm_bf16, float>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
+        else hipLaunchKernelGGL((bias_act_dropout_bwd_kernel<cm_bf16, cm_bf16>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
+    } else hipLaunchKernelGGL((bias_act_dropout_bwd_kernel<float, float>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
+    if (int rc = cm_launch_status("cm_bias_act_dropout_bwd")) return rc;
+    if (a.dbias) {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((a.dim + 31) / 32), dim3(256), 0, st, a.dbias_part, nwg, a.dim, a.dbias);
+        return cm_launch_status("cm_bias_act_dropout_bwd(reduce)");
+    }
+    return CM_OK;
+}

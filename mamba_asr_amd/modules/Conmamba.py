@@ -110,12 +110,20 @@ class ConmambaEncoderLayer(nn.Module):
             ln.low_out = True
         self.drop = nn.Dropout(dropout)
 
+    def _ffn(self, mod, x):
+        """x + 0.5 * ffn_module(x): one autograd node on rows where its kernels apply (modules/ffn_rows.py), else the module tree."""
+        from . import ffn_rows
+        ln, pff, drop = mod[0], mod[1], mod[2]
+        if ffn_rows.supported(x, ln, pff.ffn[0], pff.ffn[1], pff.ffn[3]):
+            return ffn_rows.ffn_rows(x, ln, pff.ffn[0], pff.ffn[2], pff.ffn[3], drop, FFN_RESIDUAL_SCALE)
+        return x + FFN_RESIDUAL_SCALE * mod(x)
+
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None):
         # the reference computes a conv mask and then discards it (:631-635): padding is NOT masked
-        x = x + FFN_RESIDUAL_SCALE * self.ffn_module1(x)
+        x = self._ffn(self.ffn_module1, x)
         x = self.mamba(self.norm1(x)) + x
         x = x + self.convolution_module(x, None, dynchunktrain_config=dynchunktrain_config)
-        return self.norm2(x + FFN_RESIDUAL_SCALE * self.ffn_module2(x))
+        return self.norm2(self._ffn(self.ffn_module2, x))
 
 
 class ConmambaEncoder(nn.Module):
@@ -170,6 +178,9 @@ class MambaDecoderLayer(nn.Module):
         tgt = tgt + self.dropout2(self.cross_mamba(torch.cat([memory, h], dim=1))[:, -h.shape[1]:])
         if not pre:
             tgt = self.norm2(tgt)
+        from . import ffn_rows
+        if pre and ffn_rows.supported(tgt, self.norm3.norm, self.pos_ffn.ffn[0], self.pos_ffn.ffn[1], self.pos_ffn.ffn[3]):
+            return ffn_rows.ffn_rows(tgt, self.norm3.norm, self.pos_ffn.ffn[0], self.pos_ffn.ffn[2], self.pos_ffn.ffn[3], self.dropout3, 1.0), None, None
         h = self.norm3(tgt) if pre else tgt
         tgt = tgt + self.dropout3(self.pos_ffn(h))
         if not pre:

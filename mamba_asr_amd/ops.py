@@ -442,6 +442,65 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split
     return outs
 
 
+def _elem_args(rows, dim, io_dtype, act, p, alpha):
+    a = N.FfnElemArgs()
+    a.rows, a.dim, a.io_dtype, a.act, a.p, a.alpha, a.stream = rows, dim, _DT[io_dtype], int(act), float(p), float(alpha), _stream()
+    return a
+
+
+def draw_seed() -> int:
+    """64-bit seed for a dropout mask from torch's (seedable) CPU generator: no device synchronisation."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def bias_act_dropout_fwd(a, bias, act=0, p=0.0, res=None, alpha=1.0):
+    """y = dropout(act(a + bias)) in a's dtype, or with ``res`` (fp32, a's shape) y = res + alpha * dropout(a + bias) in fp32
+    (cm_bias_act_dropout_fwd).  a (rows, dim) contiguous bf16 / fp32; act 0 none, 1 GELU.  -> (y, mask or None)."""
+    _dev_check(a, bias, res)
+    if a.dim() != 2 or not a.is_contiguous() or a.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("bias_act_dropout_fwd: a must be a contiguous (rows, dim) bf16 / fp32 tensor")
+    rows, dim = a.shape
+    args = _elem_args(rows, dim, a.dtype, act, p, alpha)
+    bs = _f32c(bias)
+    mask = torch.empty((rows, dim), dtype=torch.uint8, device=a.device) if p > 0.0 else None
+    if res is not None and (res.dtype != torch.float32 or not res.is_contiguous() or res.shape != a.shape):
+        raise RuntimeError("bias_act_dropout_fwd: res must be a contiguous fp32 tensor of a's shape")
+    y = torch.empty((rows, dim), dtype=torch.float32 if res is not None else a.dtype, device=a.device)
+    args.a, args.bias, args.res, args.y, args.mask = _ptr(a), _ptr(bs), _ptr(res), _ptr(y), _ptr(mask)
+    if mask is not None:
+        args.seed = draw_seed()
+    _launch("cm_bias_act_dropout_fwd", N.lib().cm_bias_act_dropout_fwd, args, units=rows)
+    return y, mask
+
+
+def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_dtype=None, want_dbias=True):
+    """da = alpha * dy * mask / (1 - p) * act'(a + bias) in ``out_dtype`` (default a's / dy's dtype); dbias = column sums of da
+    (fp32, deterministic) (cm_bias_act_dropout_bwd).  dy (rows, dim) fp32 or the I/O dtype.  -> (da, dbias or None)."""
+    _dev_check(dy, mask, a, bias)
+    if dy.dim() != 2 or not dy.is_contiguous():
+        raise RuntimeError("bias_act_dropout_bwd: dy must be a contiguous (rows, dim) tensor")
+    rows, dim = dy.shape
+    io = out_dtype or (a.dtype if a is not None else dy.dtype)
+    if io not in (torch.float32, torch.bfloat16) or dy.dtype not in (torch.float32, io):
+        raise RuntimeError("bias_act_dropout_bwd: dtypes must be fp32 / bf16, dy fp32 or the I/O dtype")
+    if a is not None and (a.dtype != io or not a.is_contiguous() or a.shape != dy.shape):
+        raise RuntimeError("bias_act_dropout_bwd: a must be contiguous, of dy's shape, in the I/O dtype")
+    args = _elem_args(rows, dim, io, act, p if mask is not None else 0.0, alpha)
+    bs = _f32c(bias)
+    da = torch.empty((rows, dim), dtype=io, device=dy.device)
+    args.a, args.bias, args.mask, args.dy, args.da = _ptr(a), _ptr(bs), _ptr(mask), _ptr(dy), _ptr(da)
+    args.dy_f32 = int(dy.dtype == torch.float32 and io != torch.float32)
+    dbias = None
+    if want_dbias:
+        nws = int(N.lib().cm_bias_act_dropout_bwd_workspace_floats(rows, dim))
+        ws = torch.empty((nws + dim,), dtype=torch.float32, device=dy.device)
+        dbias = ws[nws:]
+        dbias.zero_()
+        args.dbias, args.dbias_part = _ptr(dbias), _ptr(ws)
+    _launch("cm_bias_act_dropout_bwd", N.lib().cm_bias_act_dropout_bwd, args, units=rows)
+    return da, dbias
+
+
 def sum_leading(t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     """t (batch, ...) -> sum over the leading axis with fp32 accumulation in a fixed order (cm_sum_leading): folds per-utterance
     weight-gradient products; output in ``out_dtype`` (fp32 = a parameter's gradient dtype, no cast afterwards)."""

@@ -150,3 +150,49 @@ def test_conv_cl_bwd(shape, dtype, two):
     close(dbf, rdb, 1e-3 if f32 else 1e-2, 1e-4 if f32 else 2e-3)
     again = ops.conv_cl_bwd(gxz[:, :, :e], w[0].to(DEV), bs[0].to(DEV), gdu[:, :, :e], dz_f=gdz[:, :, :e], **args)
     assert torch.equal(again[0], dxz[:, :, :e]) and torch.equal(again[2], dwf) and torch.equal(again[3], dbf)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ffn_rows_node_vs_module_tree(dtype, monkeypatch):
+    """modules/ffn_rows.FfnRowsFn (fused bias + GELU + dropout / bias + dropout + residual kernels, csrc/ffn_train.hip) against the
+    same module tree run by torch (CM_FFN_ROWS off) in fp64 on the CPU: output and every gradient, dropout off; then dropout on:
+    the masks of forward and backward agree (gradient check by finite consistency), keep rate ~ 1 - p, scale 1 / (1 - p)."""
+    import torch.nn as nn
+    from mamba_asr_amd.modules import Conmamba as CM
+    from mamba_asr_amd.modules import ffn_rows
+    torch.manual_seed(3)
+    layer = CM.ConmambaEncoderLayer(d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True, dropout=0.0, causal=False,
+                                    mamba_config={"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True})
+    mod = layer.ffn_module1
+    with torch.no_grad():
+        for p_ in mod.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    x = torch.randn(3, 37, 256)
+    dy = torch.randn(3, 37, 256)
+    ref_mod = __import__("copy").deepcopy(mod).double()
+    xr = x.double().requires_grad_(True)
+    want = xr + 0.5 * ref_mod(xr)
+    gref = torch.autograd.grad(want, [xr] + list(ref_mod.parameters()), dy.double())
+    layer = layer.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        got = layer._ffn(layer.ffn_module1, xg)
+    ggot = torch.autograd.grad(got, [xg] + list(layer.ffn_module1.parameters()), dy.to(DEV))
+    rt, at = (2e-4, 2e-5) if dtype == torch.float32 else (2e-2, 1.5e-2)
+    close(got, want.detach(), rt, at)
+    for a_, b_ in zip(ggot, gref):
+        close(a_, b_, rt * 5, at)
+    # dropout on: y = x + 0.5 * drop(f): same mask in forward and backward -> d(out)/d(b2) column sums equal 0.5 * sum(dy * mask / (1 - p))
+    layer.train()
+    for m_ in layer.ffn_module1.modules():
+        if isinstance(m_, nn.Dropout):
+            m_.p = 0.25
+    xg2 = x.to(DEV).requires_grad_(True)
+    out = layer._ffn(layer.ffn_module1, xg2)
+    b2 = layer.ffn_module1[1].ffn[3].bias
+    (gb2,) = torch.autograd.grad(out, [b2], torch.ones_like(out))
+    keep = gb2 / (0.5 / 0.75)                                           # kept rows per column
+    rate = float(keep.sum() / (3 * 37 * 256))
+    assert abs(rate - 0.75) < 0.02, rate
+    assert torch.allclose(keep, keep.round(), atol=1e-3)
