@@ -362,7 +362,7 @@ typedef struct cm_conv_cl_bwd_args {
  * reference leaves them to torch: reference modules/Conmamba.py:597-617):
  *   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))  [I/O dtype]      or, with res:  y = res + alpha * dropout(a + bias)  [fp32]
  *   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias)  [I/O dtype];  dbias += column sums of da (fixed order)
- * act: 0 none, 1 GELU (erf form).  mask: one byte per element, NULL = no dropout (eval, or p == 0); the forward draws it from a
+ * act: 0 none, 1 GELU (erf form), 2 GLU (a and da are (rows, 2 dim), bias / dbias (2 dim); no dropout, no residual).  mask: one byte per element, NULL = no dropout (eval, or p == 0); the forward draws it from a
  * counter hash of (seed, element index).  dim: multiple of 8, <= 2048; tensors contiguous, 16-byte aligned. */
 typedef struct cm_ffn_elem_args {
     int64_t rows;

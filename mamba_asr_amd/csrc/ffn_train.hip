@@ -144,6 +144,83 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
     }
 }
 
+// GLU over the feature axis (the convolution module's bottleneck, reference modules/Conmamba.py:268-274, 441): a (rows, 2 dim) ->
+// y (rows, dim) = (a[:, :dim] + b[:dim]) * sigmoid(a[:, dim:] + b[dim:])
+template <typename AT>
+__global__ __launch_bounds__(256) void bias_glu_fwd_kernel(const cm_ffn_elem_args p) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int vpr = p.dim / 8;
+    if (v >= p.rows * vpr) return;
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * 8;
+    float a1[8], a2[8], y[8];
+    const AT *ar = reinterpret_cast<const AT *>(p.a) + r * 2 * p.dim;
+    ld_vec<AT>(ar + c, a1);
+    ld_vec<AT>(ar + p.dim + c, a2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = (a1[k] + (p.bias ? p.bias[c + k] : 0.f)) * cm_sigmoid(a2[k] + (p.bias ? p.bias[p.dim + c + k] : 0.f));
+    st_vec<AT>(reinterpret_cast<AT *>(p.y) + r * p.dim + c, y);
+}
+
+// da (rows, 2 dim): value half dy * sig, gate half dy * (a1 + b1) * sig * (1 - sig); dbias (2 dim) partial rows as above
+template <typename AT>
+__global__ __launch_bounds__(256) void bias_glu_bwd_kernel(const cm_ffn_elem_args p, const int rows_per_wg) {
+    __shared__ float red[256 * 16];
+    const int vpr = p.dim / 8, rp = 256 / vpr;
+    const int tr = threadIdx.x / vpr, tc = threadIdx.x % vpr;
+    const bool live = tr < rp;
+    const int c = tc * 8;
+    float b1[8], b2[8], acc[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        b1[k] = p.bias ? p.bias[live ? c + k : 0] : 0.f;
+        b2[k] = p.bias ? p.bias[live ? p.dim + c + k : 0] : 0.f;
+        acc[k] = acc[8 + k] = 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (live) {
+        for (int64_t r = r0 + tr; r < r0 + rows_per_wg && r < p.rows; r += rp) {
+            float a1[8], a2[8], dy[8], d1[8], d2[8];
+            const AT *ar = reinterpret_cast<const AT *>(p.a) + r * 2 * p.dim;
+            ld_vec<AT>(ar + c, a1);
+            ld_vec<AT>(ar + p.dim + c, a2);
+            ld_vec<AT>(reinterpret_cast<const AT *>(p.dy) + r * p.dim + c, dy);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float sg = cm_sigmoid(a2[k] + b2[k]);
+                d1[k] = dy[k] * sg;
+                d2[k] = dy[k] * (a1[k] + b1[k]) * sg * (1.f - sg);
+            }
+            AT *dr = reinterpret_cast<AT *>(p.da) + r * 2 * p.dim;
+            st_vec<AT>(dr + c, d1);
+            st_vec<AT>(dr + p.dim + c, d2);
+            if (p.dbias_part) {
+                if constexpr (sizeof(AT) == 2) {                     // sum what the GEMMs see: the rounded values
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const uint32_t w1 = cm_pack_bf16(d1[k], d1[k + 1]), w2 = cm_pack_bf16(d2[k], d2[k + 1]);
+                        d1[k] = cm_bf16_lo(w1), d1[k + 1] = cm_bf16_hi(w1), d2[k] = cm_bf16_lo(w2), d2[k + 1] = cm_bf16_hi(w2);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += d1[k], acc[8 + k] += d2[k];
+            }
+        }
+    }
+    if (!p.dbias_part) return;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[threadIdx.x * 16 + k] = acc[k];
+    __syncthreads();
+    if (live && tr == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float s = 0.f;
+            for (int j = 0; j < rp; ++j) s += red[(j * vpr + tc) * 16 + k];
+            p.dbias_part[(int64_t)blockIdx.x * 2 * p.dim + (k < 8 ? c + k : p.dim + c + k - 8)] = s;
+        }
+    }
+}
+
 // dbias[c] += sum over the partial rows, fixed order: 32 columns x 8 row groups per workgroup
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ part, const int nrow, const int dim, float *__restrict__ out) {
     __shared__ float red[8][32];
@@ -169,7 +246,8 @@ int check(const cm_ffn_elem_args &a, const char *what) {
     CM_REQUIRE(a.rows > 0 && a.dim > 0, CM_EINVAL, "%s: bad sizes", what);
     CM_REQUIRE(a.dim % 8 == 0 && a.dim <= 2048, CM_EUNSUPPORTED, "%s: dim %d must be a multiple of 8, at most 2048", what, a.dim);
     CM_REQUIRE(a.io_dtype == CM_BF16 || a.io_dtype == CM_F32, CM_EUNSUPPORTED, "%s: io dtype %d unsupported", what, a.io_dtype);
-    CM_REQUIRE(a.act == 0 || a.act == 1, CM_EUNSUPPORTED, "%s: act %d (0 none, 1 GELU)", what, a.act);
+    CM_REQUIRE(a.act >= 0 && a.act <= 2, CM_EUNSUPPORTED, "%s: act %d (0 none, 1 GELU, 2 GLU)", what, a.act);
+    CM_REQUIRE(a.act != 2 || (!a.mask && !a.res && a.dim <= 1024), CM_EUNSUPPORTED, "%s: GLU takes no dropout / residual, dim <= 1024", what);
     CM_REQUIRE(!a.mask || (a.p > 0.f && a.p < 1.f && cm_aligned(a.mask, 8)), CM_EINVAL, "%s: mask needs 0 < p < 1 and 8-byte alignment", what);
     return CM_OK;
 }
@@ -178,7 +256,7 @@ int check(const cm_ffn_elem_args &a, const char *what) {
 
 extern "C" int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim) {
     if (rows <= 0 || dim <= 0) return 0;
-    return ((rows + ROWS_PER_WG - 1) / ROWS_PER_WG) * dim;
+    return ((rows + ROWS_PER_WG - 1) / ROWS_PER_WG) * 2 * dim;      // 2 dim columns: the GLU form's bias gradient
 }
 
 extern "C" int cm_bias_act_dropout_fwd(const cm_ffn_elem_args *args) {
@@ -190,6 +268,11 @@ extern "C" int cm_bias_act_dropout_fwd(const cm_ffn_elem_args *args) {
     const int64_t threads = a.rows * (a.dim / 8);
     const dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    if (a.act == 2) {
+        if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((bias_glu_fwd_kernel<cm_bf16>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bias_glu_fwd_kernel<float>), grid, dim3(256), 0, st, a);
+        return cm_launch_status("cm_bias_act_dropout_fwd(glu)");
+    }
     const bool yf = a.res != nullptr || a.io_dtype == CM_F32;        // the residual form writes the fp32 stream
     if (a.io_dtype == CM_BF16) {
         if (yf) hipLaunchKernelGGL((bias_act_dropout_fwd_kernel<cm_bf16, float>), grid, dim3(256), 0, st, a);
@@ -208,6 +291,17 @@ extern "C" int cm_bias_act_dropout_bwd(const cm_ffn_elem_args *args) {
     const int nwg = (int)((a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     const bool dyf = a.dy_f32 != 0 || a.io_dtype == CM_F32;
+    if (a.act == 2) {
+        CM_REQUIRE(!a.dy_f32 || a.io_dtype == CM_F32, CM_EUNSUPPORTED, "bias_act_dropout_bwd: the GLU form takes dy in the I/O dtype");
+        if (a.io_dtype == CM_BF16) hipLaunchKernelGGL((bias_glu_bwd_kernel<cm_bf16>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
+        else hipLaunchKernelGGL((bias_glu_bwd_kernel<float>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
+        if (int rc = cm_launch_status("cm_bias_act_dropout_bwd(glu)")) return rc;
+        if (a.dbias) {
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * a.dim + 31) / 32), dim3(256), 0, st, a.dbias_part, nwg, 2 * a.dim, a.dbias);
+            return cm_launch_status("cm_bias_act_dropout_bwd(glu reduce)");
+        }
+        return CM_OK;
+    }
     if (a.io_dtype == CM_BF16) {
         if (dyf) hipLaunchKernelGGL((bias_act_dropout_bwd_kernel<cm_bf16, float>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);
         else hipLaunchKernelGGL((bias_act_dropout_bwd_kernel<cm_bf16, cm_bf16>), dim3(nwg), dim3(256), 0, st, a, ROWS_PER_WG);

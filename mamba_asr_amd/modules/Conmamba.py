@@ -122,7 +122,11 @@ class ConmambaEncoderLayer(nn.Module):
         # the reference computes a conv mask and then discards it (:631-635): padding is NOT masked
         x = self._ffn(self.ffn_module1, x)
         x = self.mamba(self.norm1(x)) + x
-        x = x + self.convolution_module(x, None, dynchunktrain_config=dynchunktrain_config)
+        from . import convmod_rows
+        if dynchunktrain_config is None and convmod_rows.supported(self.convolution_module, x):
+            x = convmod_rows.convmod_rows(self.convolution_module, x)         # x + convolution_module(x) as one node on rows
+        else:
+            x = x + self.convolution_module(x, None, dynchunktrain_config=dynchunktrain_config)
         return self.norm2(self._ffn(self.ffn_module2, x))
 
 

@@ -501,6 +501,38 @@ def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_d
     return da, dbias
 
 
+def bias_glu_fwd(a, bias):
+    """(rows, 2 dim) -> (rows, dim): (a[:, :dim] + b[:dim]) * sigmoid(a[:, dim:] + b[dim:])  (cm_bias_act_dropout_fwd, act 2)."""
+    _dev_check(a, bias)
+    rows, d2 = a.shape
+    if not a.is_contiguous() or a.dtype not in (torch.float32, torch.bfloat16) or d2 % 16:
+        raise RuntimeError("bias_glu_fwd: a must be a contiguous (rows, 2 dim) bf16 / fp32 tensor, dim a multiple of 8")
+    args = _elem_args(rows, d2 // 2, a.dtype, 2, 0.0, 1.0)
+    bs = _f32c(bias)
+    y = torch.empty((rows, d2 // 2), dtype=a.dtype, device=a.device)
+    args.a, args.bias, args.y = _ptr(a), _ptr(bs), _ptr(y)
+    _launch("cm_bias_act_dropout_fwd", N.lib().cm_bias_act_dropout_fwd, args, units=rows)
+    return y
+
+
+def bias_glu_bwd(dy, a, bias):
+    """-> (da (rows, 2 dim) in a's dtype, dbias (2 dim) fp32) of bias_glu_fwd (cm_bias_act_dropout_bwd, act 2; deterministic)."""
+    _dev_check(dy, a, bias)
+    rows, d = dy.shape
+    if not dy.is_contiguous() or dy.dtype != a.dtype or a.shape != (rows, 2 * d) or not a.is_contiguous():
+        raise RuntimeError("bias_glu_bwd: dy (rows, dim) and a (rows, 2 dim) must be contiguous and share a dtype")
+    args = _elem_args(rows, d, a.dtype, 2, 0.0, 1.0)
+    bs = _f32c(bias)
+    da = torch.empty_like(a)
+    nws = int(N.lib().cm_bias_act_dropout_bwd_workspace_floats(rows, d))
+    ws = torch.empty((nws + 2 * d,), dtype=torch.float32, device=dy.device)
+    dbias = ws[nws:]
+    dbias.zero_()
+    args.a, args.bias, args.dy, args.da, args.dbias, args.dbias_part = _ptr(a), _ptr(bs), _ptr(dy), _ptr(da), _ptr(dbias), _ptr(ws)
+    _launch("cm_bias_act_dropout_bwd", N.lib().cm_bias_act_dropout_bwd, args, units=rows)
+    return da, dbias
+
+
 def sum_leading(t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     """t (batch, ...) -> sum over the leading axis with fp32 accumulation in a fixed order (cm_sum_leading): folds per-utterance
     weight-gradient products; output in ``out_dtype`` (fp32 = a parameter's gradient dtype, no cast afterwards)."""

@@ -196,3 +196,35 @@ def test_ffn_rows_node_vs_module_tree(dtype, monkeypatch):
     rate = float(keep.sum() / (3 * 37 * 256))
     assert abs(rate - 0.75) < 0.02, rate
     assert torch.allclose(keep, keep.round(), atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_convmod_rows_node_vs_module_tree(dtype, causal):
+    """modules/convmod_rows.ConvModuleRowsFn against the module tree (reference modules/Conmamba.py:439-449 semantics, pinned by
+    G4) run by torch in fp64 on the CPU: x + convolution_module(x) and every gradient."""
+    import copy
+    import torch.nn as nn
+    from mamba_asr_amd.modules import Conmamba as CM
+    from mamba_asr_amd.modules import convmod_rows
+    torch.manual_seed(4)
+    cm = CM.ConvolutionModule(256, 31, True, nn.GELU, 0.0, causal=causal)
+    with torch.no_grad():
+        for p_ in cm.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    x, dy = torch.randn(3, 50, 256), torch.randn(3, 50, 256)
+    ref = copy.deepcopy(cm).double()
+    xr = x.double().requires_grad_(True)
+    want = xr + ref(xr)
+    gref = torch.autograd.grad(want, [xr] + list(ref.parameters()), dy.double())
+    cm = cm.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    assert convmod_rows.supported(cm, xg)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        got = convmod_rows.convmod_rows(cm, xg)
+    ggot = torch.autograd.grad(got, [xg] + list(cm.parameters()), dy.to(DEV))
+    rt, at = (2e-4, 2e-5) if dtype == torch.float32 else (2e-2, 1.5e-2)
+    close(got, want.detach(), rt, at)
+    for (k, _), a_, b_ in zip([("x", None)] + list(cm.named_parameters()), ggot, gref):
+        close(a_, b_, rt * 5, at * 2)
