@@ -595,6 +595,8 @@ typedef struct cm_layernorm_args {
     float *dgamma, *dbeta;
     float *workspace;
     void  *stream;
+    const float *dres;           /* backward, optional: (rows, dim) fp32 added to dx (the residual branch's gradient: the
+                                    pre-norm block's dx = dres + LayerNorm'(dy) in one pass); fp32 x and dim <= 1024 only */
 } cm_layernorm_args;
 
 int64_t cm_layernorm_bwd_workspace_floats(int64_t rows, int32_t dim);

@@ -169,10 +169,11 @@ class DwconvClArgs(C.Structure):
 
 
 class LayerNormArgs(C.Structure):
+    # (dres appended in ABI 7)
     _fields_ = [
         ("rows", i64), ("dim", i32), ("x_dtype", i32), ("y_dtype", i32), ("eps", C.c_float),
         ("x", vp), ("gamma", fp), ("beta", fp), ("y", vp), ("mean", fp), ("rstd", fp),
-        ("dy", vp), ("dx", vp), ("dgamma", fp), ("dbeta", fp), ("workspace", fp), ("stream", vp),
+        ("dy", vp), ("dx", vp), ("dgamma", fp), ("dbeta", fp), ("workspace", fp), ("stream", vp), ("dres", fp),
     ]
 
 

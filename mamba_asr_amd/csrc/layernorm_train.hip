@@ -144,10 +144,15 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
         if (ok && dx) {
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
-                if (on[i])
-                    st4(dx + row * dim + 4 * (lr + LPR * i),
-                        make_float4(rstd * (gy[i].x - c1 - xh[i].x * c2), rstd * (gy[i].y - c1 - xh[i].y * c2),
-                                    rstd * (gy[i].z - c1 - xh[i].z * c2), rstd * (gy[i].w - c1 - xh[i].w * c2)));
+                if (on[i]) {
+                    float4 o = make_float4(rstd * (gy[i].x - c1 - xh[i].x * c2), rstd * (gy[i].y - c1 - xh[i].y * c2),
+                                           rstd * (gy[i].z - c1 - xh[i].z * c2), rstd * (gy[i].w - c1 - xh[i].w * c2));
+                    if (p.dres) {                                  // + the residual branch's gradient (pre-norm block)
+                        const float4 r = *reinterpret_cast<const float4 *>(p.dres + row * dim + 4 * (lr + LPR * i));
+                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+                    }
+                    st4(dx + row * dim + 4 * (lr + LPR * i), o);
+                }
             }
         }
     }
@@ -396,5 +401,7 @@ extern "C" int cm_layernorm_bwd(const cm_layernorm_args *args) {
     CM_REQUIRE(a.dy && a.mean && a.rstd && a.dgamma && a.dbeta && a.workspace, CM_EINVAL,
                "layernorm_bwd: dy / mean / rstd / dgamma / dbeta / workspace must be non-NULL");
     CM_REQUIRE(cm_aligned(a.dy, 16) && (!a.dx || cm_aligned(a.dx, 16)), CM_EALIGN, "layernorm_bwd: tensors must be 16-byte aligned");
+    CM_REQUIRE(!a.dres || (a.dx && a.x_dtype == CM_F32 && a.dim <= 1024 && cm_aligned(a.dres, 16)), CM_EUNSUPPORTED,
+               "layernorm_bwd: dres needs dx, fp32 x, dim <= 1024 and 16-byte alignment");
     return a.dim > 1024 ? dispatch_wide(a, true) : dispatch<BwdLaunch>(a);
 }

@@ -121,7 +121,11 @@ class ConmambaEncoderLayer(nn.Module):
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, dynchunktrain_config=None):
         # the reference computes a conv mask and then discards it (:631-635): padding is NOT masked
         x = self._ffn(self.ffn_module1, x)
-        x = self.mamba(self.norm1(x)) + x
+        from .mamba import mixer_rows
+        if mixer_rows.block_supported(self.mamba, self.norm1.norm, x):
+            x = mixer_rows.mixer_rows(self.mamba, x, ln=self.norm1.norm)                # x + mamba(norm1(x)) as one node on rows
+        else:
+            x = self.mamba(self.norm1(x)) + x
         from . import convmod_rows
         if dynchunktrain_config is None and convmod_rows.supported(self.convolution_module, x):
             x = convmod_rows.convmod_rows(self.convolution_module, x)         # x + convolution_module(x) as one node on rows

@@ -72,8 +72,8 @@ class ConvModuleRowsFn(torch.autograd.Function):
         wpw = ops.cast_cached(pww, cdt).view(2 * D, D)
         dh = torch.mm(da_pw, wpw)
         dpww = ops.sum_leading(torch.bmm(da_pw.view(B, T, 2 * D).transpose(1, 2), h.view(B, T, D))).view(pww.shape)
-        dx_ln, dln1w, dln1b = ops.layernorm_bwd(dh, x2s, st1, ln1w, eps1)
-        dx = (dout2 + dx_ln).view(B, T, D)
+        dx, dln1w, dln1b = ops.layernorm_bwd(dh, x2s, st1, ln1w, eps1, dres=dout2)     # dx = dout + LayerNorm'(dh) in one pass
+        dx = dx.view(B, T, D)
         return (dx, dln1w, dln1b, dpww, dpwb, dcw.reshape(cw.shape), dcb, dln2w, dln2b, dlw, db_l, None, None, None, None)
 
 

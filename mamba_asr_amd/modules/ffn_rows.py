@@ -68,8 +68,8 @@ class FfnRowsFn(torch.autograd.Function):
         da1, db1 = ops.bias_act_dropout_bwd(dg, m1, p1, a=a1, bias=b1, act=1)
         dh = torch.mm(da1, w1c)
         dw1 = ops.sum_leading(torch.bmm(da1.view(B, T, F_).transpose(1, 2), h.view(B, T, D)))
-        dx_ln, dlnw, dlnb = ops.layernorm_bwd(dh, x2s, stats, lnw, eps)
-        dx = (dout2 + dx_ln).view(B, T, D)
+        dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2s, stats, lnw, eps, dres=dout2)       # dx = dout + LayerNorm'(dh) in one pass
+        dx = dx.view(B, T, D)
         return dx, dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None
 
 

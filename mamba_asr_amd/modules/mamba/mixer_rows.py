@@ -86,15 +86,23 @@ class MixerRowsFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, hidden, m, sfx, scale, *params):
+    def forward(ctx, hidden, m, sfx, scale, ln, *params):
         cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden.dtype
         dv = _derived(m, sfx, cdt, scale)
         ndir = len(sfx)
         B, T, D = hidden.shape
         E, R, P, RW = m.d_inner, m.dt_rank, dv.P, dv.RW
         dev = hidden.device
-        h2 = hidden.detach().to(cdt)
-        h2 = h2 if h2.is_contiguous() else h2.contiguous()
+        x2s = stats = None
+        if ln is not None:
+            # pre-norm block: out = hidden + mixer(LayerNorm(hidden)) (reference Conmamba.py:641-643); hidden = the fp32 residual stream
+            x2 = hidden.detach().reshape(B * T, D)
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            h2, x2s, stats = ops.layernorm_fwd(x2, ln.weight, ln.bias, ln.eps, cdt)
+            h2 = h2.view(B, T, D)
+        else:
+            h2 = hidden.detach().to(cdt)
+            h2 = h2 if h2.is_contiguous() else h2.contiguous()
         xz = torch.mm(h2.view(B * T, D), dv.w_in.t()).view(B, T, 2 * E)
         x, z = xz[:, :, :E], xz[:, :, E:]
         convs = [getattr(m, "conv1d" + s) for s in sfx]
@@ -126,16 +134,24 @@ class MixerRowsFn(torch.autograd.Function):
             dirs.append(dd)
         ops.scan_cl_fwd(dirs, z=z, delta_softplus=True)
         out = torch.mm(ycat.view(B * T, ndir * E), dv.w_out_cat.t()).view(B, T, D)
+        if ln is not None:
+            out = x2s.view(B, T, D) + out                                               # fp32 stream
         if need_grad:
-            ctx.m, ctx.sfx, ctx.scale, ctx.dv, ctx.cdt = m, sfx, scale, dv, cdt
-            ctx.save_for_backward(h2, xz, ucat, xdbl, pcat, ycat, *cks)
+            ctx.m, ctx.sfx, ctx.scale, ctx.dv, ctx.cdt, ctx.ln = m, sfx, scale, dv, cdt, ln
+            ctx.save_for_backward(h2, xz, ucat, xdbl, pcat, ycat, x2s, stats, *cks)
         return out
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, dY):
         m, sfx, scale, dv, cdt = ctx.m, ctx.sfx, ctx.scale, ctx.dv, ctx.cdt
-        h2, xz, ucat, xdbl, pcat, ycat, *cks = ctx.saved_tensors
+        h2, xz, ucat, xdbl, pcat, ycat, x2s, stats, *cks = ctx.saved_tensors
+        ln = ctx.ln
+        dres = None
+        if ln is not None:
+            dres = dY.reshape(-1, dY.shape[-1])
+            dres = (dres if dres.dtype == torch.float32 else dres.float())
+            dres = dres if dres.is_contiguous() else dres.contiguous()
         ndir = len(sfx)
         B, T, D = h2.shape
         E, R, P, RW = m.d_inner, m.dt_rank, dv.P, dv.RW
@@ -179,7 +195,11 @@ class MixerRowsFn(torch.autograd.Function):
         else:
             _, _, dwf, dbf, _, _ = ops.conv_cl_bwd(x, cw[0], cb[0], ducat, dx=dxz[:, :, :E])
             dconv = [(dwf, dbf)]
-        d_hidden = torch.mm(dxz.view(B * T, 2 * E), dv.w_in).view(B, T, D) if ctx.needs_input_grad[0] else None
+        d_hidden = torch.mm(dxz.view(B * T, 2 * E), dv.w_in).view(B, T, D) if (ctx.needs_input_grad[0] or ln is not None) else None
+        dln = (None, None)
+        if ln is not None:                                                              # dx = dY + LayerNorm'(dh) in one pass
+            d_hidden, dlw, dlb = ops.layernorm_bwd(d_hidden.view(B * T, D), x2s, stats, ln.weight, ln.eps, dres=dres)
+            d_hidden, dln = d_hidden.view(B, T, D), (dlw, dlb)
         d_in_w = ops.sum_leading(torch.bmm(dxz.transpose(1, 2), h2))                   # (2E, D)
         for i, s in enumerate(sfx):
             r = res[i]
@@ -187,11 +207,14 @@ class MixerRowsFn(torch.autograd.Function):
             grads += [dconv[i][0].reshape(convs[i].weight.shape), dconv[i][1], dxw, r["ddt_weight"][:, :R], r["ddelta_bias"],
                       r["dA"] * dv.A[i], r["dD"]]
         grads += [d_in_w, d_out_w]
-        return (d_hidden, None, None, None, *grads)
+        if ln is not None:
+            grads += [dln[0], dln[1]]
+        return (d_hidden, None, None, None, None, *grads)
 
 
-def mixer_rows(m, hidden):
-    """Run module ``m`` (bimamba.Mamba v2 or bimamba.UniMamba) on the rows node; caller checked ``supported``."""
+def mixer_rows(m, hidden, ln=None):
+    """Run module ``m`` (bimamba.Mamba v2 or bimamba.UniMamba) on the rows node; caller checked ``supported``.
+    With ``ln`` (an nn.LayerNorm over the last axis): the pre-norm block hidden + m(ln(hidden)) on the fp32 residual stream."""
     bidir = hasattr(m, "A_b_log")
     sfx = ("", "_b") if bidir else ("",)
     scale = 0.5 if (bidir and m.if_devide_out) else 1.0
@@ -200,4 +223,11 @@ def mixer_rows(m, hidden):
         conv, xp, dtp = getattr(m, "conv1d" + s), getattr(m, "x_proj" + s), getattr(m, "dt_proj" + s)
         params += [conv.weight, conv.bias, xp.weight, dtp.weight, dtp.bias, getattr(m, "A_b_log" if s else "A_log"), getattr(m, "D_b" if s else "D")]
     params += [m.in_proj.weight, m.out_proj.weight]
-    return MixerRowsFn.apply(hidden, m, sfx, scale, *params)
+    if ln is not None:
+        params += [ln.weight, ln.bias]
+    return MixerRowsFn.apply(hidden, m, sfx, scale, ln, *params)
+
+
+def block_supported(m, ln, x) -> bool:
+    return (supported(m, x) and x.dtype == torch.float32 and ln.weight is not None and ln.bias is not None
+            and len(ln.normalized_shape) == 1 and x.shape[-1] <= 1024)

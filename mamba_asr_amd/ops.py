@@ -933,8 +933,9 @@ def layernorm_fwd(x, weight, bias, eps, out_dtype=None):
     return y.view(x.shape), x2, stats
 
 
-def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True):
-    """-> (dx (x2's dtype and shape) or None, dgamma, dbeta (dim) fp32) of layernorm_fwd (cm_layernorm_bwd, deterministic)."""
+def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True, dres=None):
+    """-> (dx (x2's dtype and shape) or None, dgamma, dbeta (dim) fp32) of layernorm_fwd (cm_layernorm_bwd, deterministic).
+    ``dres`` (fp32, x2's shape; fp32 x2, dim <= 1024): added to dx in the same pass (the residual branch's gradient)."""
     _dev_check(dy, x2, stats, weight)
     dy2 = dy.reshape(x2.shape)
     if not dy2.is_contiguous():
@@ -946,7 +947,15 @@ def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True):
     a = _layernorm_args(x2, w, eps, dy2.dtype)
     a.mean, a.rstd, a.dy, a.dx = _ptr(stats[0]), _ptr(stats[1]), _ptr(dy2), _ptr(dx)
     a.dgamma, a.dbeta, a.workspace = _ptr(dgb[0]), _ptr(dgb[1]), _ptr(ws)
+    fused_res = dres is not None and need_dx and x2.dtype == torch.float32 and x2.shape[1] <= 1024
+    if fused_res:
+        _dev_check(dres)
+        if dres.dtype != torch.float32 or not dres.is_contiguous() or dres.shape != x2.shape:
+            raise RuntimeError("layernorm_bwd: dres must be a contiguous fp32 tensor of x2's shape")
+        a.dres = _ptr(dres)
     _launch("cm_layernorm_bwd", N.lib().cm_layernorm_bwd, a, units=x2.shape[0])
+    if dres is not None and need_dx and not fused_res:
+        dx = dx + dres
     return dx, dgb[0], dgb[1]
 
 
