@@ -49,7 +49,7 @@ def parse():
                          "\"survey_b16\": the forward at SURVEY §8d's 16 x 40 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 2)")
-    ap.add_argument("--stream-mode", choices=["join", "free"], default=None,
+    ap.add_argument("--stream-mode", choices=["join", "free", "pair"], default=None,
                     help="join (default): the scan runs once per layer on the whole batch; free: fully independent parts")
     ap.add_argument("--cpu-frames", type=int, default=4000, help="frames per utterance of the CPU-baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=64, help="utterances in the CPU-baseline sample")
