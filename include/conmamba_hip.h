@@ -258,7 +258,9 @@ typedef struct cm_scan_cl_args {
     void *stream;
     void   *workspace;       /* time_chunks > 1: cm_scan_cl_fwd_workspace_bytes(args) bytes, 16-byte aligned, caller owned */
     int64_t workspace_bytes;
-    int32_t lanes_per_channel; /* tuning, state-split kernel (no xdbl) only: 4, 8 or 16 lanes per channel; 0 = automatic */
+    int32_t lanes_per_channel; /* tuning: lanes a channel's 16 states are spread over.  State-split kernel (no xdbl): 4, 8 or
+                                  16; xdbl mode: 4 (scan_rows_fwd.hip) or 8 (scan_rows_fwd2.hip: z + softplus, dt_rank <= 16,
+                                  unchunked; measured slower at every size, never chosen automatically); 0 = automatic  */
     int32_t pad5_;
 } cm_scan_cl_args;
 

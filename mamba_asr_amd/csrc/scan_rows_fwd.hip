@@ -435,6 +435,10 @@ int launch_rows_chunked(const cm_scan_cl_args &a, rows_plan pl) {
     return cm_launch_status("cm_scan_cl_fwd(rows, chunked)");
 }
 
+}  // namespace
+int cm_scan_rows_fwd2(const cm_scan_cl_args &a);        // scan_rows_fwd2.hip: 2 states per lane
+namespace {
+
 template <typename IO>
 int launch_rows(const cm_scan_cl_args &a) {
     rows_plan pl{};
@@ -457,6 +461,11 @@ int launch_rows(const cm_scan_cl_args &a) {
         return launch_rows_chunked<IO, 16>(a, pl);
     }
     const long total = (long)pl.nx * a.batch * a.ndir;
+    // lanes_per_channel == 8: the 2-states-per-lane kernel (scan_rows_fwd2.hip: twice the waves for the same launch).  Measured
+    // (tools/bench_scan_small.py, profiles/r03/scan_small_batches.log) it is SLOWER at every size -- 16 x 1000 x 512: 133.7 vs
+    // 110.6 us, 32 x: 191.6 vs 145.4 -- because what a SIMD with one 4-state wave lacks is independent recurrence chains, and
+    // two 2-state waves carry exactly as many (plus 1.3x the owner / staging work); it is therefore never chosen by size.
+    if (a.lanes_per_channel == 8 && a.z && a.delta_softplus && a.dir[0].dt_rank <= 16 && cm_debug_get() == 0) return cm_scan_rows_fwd2(a);
     const dim3 grid((unsigned)total), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     if constexpr (sizeof(IO) == 2) {

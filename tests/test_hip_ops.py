@@ -230,7 +230,8 @@ def test_scan_channels_last_in_kernel_dt_proj(ops, rank):
 @pytest.mark.parametrize("shape", [(2, 37, 128), (1, 1000, 288), (3, 64, 64), (2, 5, 72), (1, 16, 512), (2, 333, 512)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rank", [9, 16, 24, 32])
-def test_scan_rows_two_directions(ops, shape, dtype, rank):
+@pytest.mark.parametrize("lanes", [4, 8])
+def test_scan_rows_two_directions(ops, shape, dtype, rank, lanes):
     """cm_scan_cl_fwd in xdbl mode (row-group kernel, csrc/scan_rows_fwd.hip): x_proj output rows [dt16 | B | C]
     (dt_rank <= 16) or [dt32 | B | C] (dt_rank <= 32, bf16: the S2S-large encoder's rank) read as written, delta
     formed in-kernel on the matrix pipe, both directions in one launch — against the fp64 oracle on the same
@@ -238,6 +239,8 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     b, l, e = shape
     P = 16 if rank <= 16 else 32                                        # width the dt features are zero-padded to
     RW = P + 32
+    if lanes == 8 and rank > 16:
+        pytest.skip("the 2-states-per-lane kernel (scan_rows_fwd2.hip) is built for dt_rank <= 16")
     if P == 32 and dtype == torch.float32:
         u = torch.zeros(1, 16, 64, device=DEV)
         with pytest.raises(RuntimeError, match="64 wide"):
@@ -273,11 +276,12 @@ def test_scan_rows_two_directions(ops, shape, dtype, rank):
     gx = xcat.to(DEV)
     for i in range(2):
         dirs[i]["xdbl"] = gx[:, :, RW * i:RW * (i + 1)]
-    ops.scan_cl_fwd(dirs, z=xz.to(DEV)[:, :, e:], delta_softplus=True)
+    # lanes 4: 4 states per lane (scan_rows_fwd.hip); lanes 8: 2 states per lane (scan_rows_fwd2.hip, what small launches get)
+    ops.scan_cl_fwd(dirs, z=xz.to(DEV)[:, :, e:], delta_softplus=True, split=lanes, time_chunks=1)
     tol = (2e-4, 5e-5) if dtype == torch.float32 else (1.6e-2, 1e-2)
     close(ycat[:, :, :e].float(), refs[0], *tol)
     close(ycat[:, :, e:].float(), refs[1], *tol)
-    if l > 64:
+    if l > 64 or lanes == 8:
         return                      # raw (un-softplused) random time steps grow the state without bound on long inputs
     # single direction, no z, no D, no bias, no softplus
     (got,) = ops.scan_cl_fwd([dict(u=dirs[0]["u"], A=dirs[0]["A"], dt_weight=dirs[0]["dt_weight"], xdbl=dirs[0]["xdbl"])],

@@ -16,7 +16,7 @@ def close(a, b, rtol, atol):
     torch.testing.assert_close(a.detach().double().cpu(), b.detach().double().cpu(), rtol=rtol, atol=atol * scale)
 
 
-def _case(ops, b, l, e, rank, dtype, seed):
+def _case(ops, b, l, e, rank, dtype, seed, lanes=0):
     P = 16 if rank <= 16 else 32
     RW = P + 32
     gen = torch.Generator().manual_seed(seed)
@@ -52,7 +52,7 @@ def _case(ops, b, l, e, rank, dtype, seed):
         dirs.append(dict(u=gu[:, :, e * i:e * (i + 1)], xdbl=gx[:, :, RW * i:RW * (i + 1)], A=A.to(DEV), D=D.to(DEV), delta_bias=bias.to(DEV),
                          dt_weight=ops.pad_dt_weight(Wdt.to(DEV)), reverse=rev, out=ycat[:, :, e * i:e * (i + 1)],
                          ypre=pcat[:, :, e * i:e * (i + 1)], ckpt=torch.empty(ops.scan_ckpt_shape(b, l, e), device=DEV)))
-    ops.scan_cl_fwd(dirs, z=gz, delta_softplus=True, time_chunks=1)
+    ops.scan_cl_fwd(dirs, z=gz, delta_softplus=True, time_chunks=1, split=lanes)
     for dd in dirs:
         dd["dout"] = gd
     return dirs, gz, refs, rank, P
@@ -87,12 +87,18 @@ def test_scan_rows_bwd_two_directions(shape, dtype, rank):
             assert torch.equal(o[k], o2[k]), k
 
 
-def test_scan_rows_fwd_training_outputs():
+@pytest.mark.parametrize("lanes", [4, 8])
+def test_scan_rows_fwd_training_outputs(lanes):
     """The training forward's extra outputs: ypre * silu(z) == out (up to the output rounding), checkpoints == the states a
-    sequence cut at the half-block boundary carries (h_last of the prefix), for both directions."""
+    sequence cut at the half-block boundary carries (h_last of the prefix), for both directions and both lane splits; the
+    backward on the 2-states-per-lane forward's checkpoints == on the 4-states-per-lane one's."""
     from mamba_asr_amd import ops
     b, l, e = 2, 75, 64
-    dirs, gz, refs, rank, P = _case(ops, b, l, e, 16, torch.float32, seed=5)
+    dirs, gz, refs, rank, P = _case(ops, b, l, e, 16, torch.float32, seed=5, lanes=lanes)
+    outs = ops.scan_cl_bwd(dirs, gz)
+    for o, r in zip(outs, refs):
+        close(o["du"].float(), r["du"].transpose(1, 2), 2e-3, 2e-4)
+        close(o["dA"], r["dA"], 3e-3, 3e-4)
     for i, dd in enumerate(dirs):
         y, yp = dd["out"], dd["ypre"]
         torch.testing.assert_close(y, yp * torch.nn.functional.silu(gz), rtol=1e-5, atol=1e-6)
@@ -107,7 +113,7 @@ def test_scan_rows_fwd_training_outputs():
             hl = torch.zeros(b, e, 16, device=DEV)
             sub = dict(u=dd["u"][:, lo:hi], xdbl=dd["xdbl"][:, lo:hi], A=dd["A"], D=dd["D"], delta_bias=dd["delta_bias"],
                        dt_weight=dd["dt_weight"], reverse=rev, h_last=hl)
-            ops.scan_cl_fwd([sub], z=gz[:, lo:hi], delta_softplus=True, time_chunks=1)
+            ops.scan_cl_fwd([sub], z=gz[:, lo:hi], delta_softplus=True, time_chunks=1, split=lanes)
             torch.testing.assert_close(ck[:, m], hl, rtol=1e-5, atol=1e-6)
 
 
