@@ -91,6 +91,186 @@ __global__ __launch_bounds__(256) void dwconv_cl_bwd_kernel(const cm_dwconv_cl_a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tiled kernels (round 3): the thread-per-channel kernels above read 2 bytes per lane and hold a 47-row register window
+// (fwd 64 us, bwd 155 us per 32 x 1000 x 256 bf16 call: 0.3-0.8 TB/s).  Here a workgroup stages a tile of 32 steps + halo of
+// 256 channels in LDS with 16-byte loads, a thread owns (channel pair, half of the steps), and the taps are v_pk_fma_f32 on
+// the pair, accumulated BY INPUT ROW (each staged row is read once per use side): the layout of the inference path's
+// dwconv_rows_kernel.  Backward = the same correlation over dy with flipped taps for dx, then the tap gradients by x row
+// with the 16 dy values of the thread in registers; partial rows per workgroup as before (fixed-order second pass).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int TT2 = 32, CB = 256, HS = 16;          // steps per tile, channels per workgroup, steps per thread
+constexpr int ROWS2 = TT2 + KMAX - 1;               // staged rows per tile
+
+template <typename IO> __device__ __forceinline__ v2f ld_pair(const unsigned char *tile, int row, int pair) {
+    if constexpr (sizeof(IO) == 2) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(tile + (row * CB + 2 * pair) * 2);
+        return v2f{cm_bf16_lo(w), cm_bf16_hi(w)};
+    } else {
+        const float2 f = *reinterpret_cast<const float2 *>(tile + (row * CB + 2 * pair) * 4);
+        return v2f{f.x, f.y};
+    }
+}
+template <typename IO> __device__ __forceinline__ void st_pair(IO *dst, v2f v) {
+    if constexpr (sizeof(IO) == 2) *reinterpret_cast<uint32_t *>(dst) = cm_pack_bf16(v.x, v.y);
+    else *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+}
+
+// rows [t_first, t_first + ROWS2) x channels [c0, c0 + CB) of src -> tile (zero outside the sequence / past dim)
+template <typename IO>
+__device__ __forceinline__ void stage_tile(unsigned char *tile, const IO *src, int64_t ts, int t_first, int T, int c0, int D) {
+    constexpr int VEC = cm_elem<IO>::kVec, CPR = CB / VEC;
+    for (int i = threadIdx.x; i < ROWS2 * CPR; i += 256) {
+        const int r = i / CPR, ch = c0 + (i % CPR) * VEC, t = t_first + r;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t >= 0 && t < T && ch < D) v = *reinterpret_cast<const uint4 *>(src + (int64_t)t * ts + ch);
+        *reinterpret_cast<uint4 *>(tile + (size_t)i * 16) = v;
+    }
+}
+
+// the workgroup's taps, (channels c0 .. c0 + CB) x K floats contiguous in memory, through LDS: coalesced loads instead of 62
+// stride-K loads per thread (measured: those loads, not the arithmetic, set the first version's 43 / 71 us).  -> w[k] of the
+// thread's channel pair, flipped when asked.  Uses the tile region: call before staging, it ends with a barrier.
+__device__ __forceinline__ void load_taps(float *scratch, const float *weight, int c0, int D, int K, int pair, bool flip, v2f (&w)[KMAX]) {
+    const int n = min(CB, D - c0) * K;
+    for (int i = threadIdx.x; i < n; i += 256) scratch[i] = weight[(int64_t)c0 * K + i];
+    __syncthreads();
+    const bool ok = c0 + 2 * pair < D;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int kk = flip ? K - 1 - k : k;
+        w[k] = (ok && k < K) ? v2f{scratch[(2 * pair) * K + kk], scratch[(2 * pair + 1) * K + kk]} : v2f{0.f, 0.f};
+    }
+    __syncthreads();
+}
+
+// acc[j] += sum_k w[k] * tile[row0 + j + k], j < HS, accumulated by input row
+template <typename IO>
+__device__ __forceinline__ void corr16(const unsigned char *tile, int row0, int pair, const v2f (&w)[KMAX], v2f (&acc)[HS]) {
+#pragma unroll
+    for (int r = 0; r < HS + KMAX - 1; ++r) {
+        const v2f xv = ld_pair<IO>(tile, row0 + r, pair);
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+            const int k = r - j;
+            if (k >= 0 && k < KMAX) acc[j] = __builtin_elementwise_fma(w[k], xv, acc[j]);
+        }
+    }
+}
+
+template <typename IO>
+__global__ __launch_bounds__(256) void dwconv_cl_fwd_tiled_kernel(const cm_dwconv_cl_args p, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int T = p.seqlen, K = p.ksize, D = p.dim;
+    const int b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * TT2, c0 = blockIdx.y * CB;
+    const int pair = threadIdx.x & 127, hf = threadIdx.x >> 7, c = c0 + 2 * pair;
+    const IO *x = reinterpret_cast<const IO *>(p.x) + (int64_t)b * p.x_bs;
+    IO *y = reinterpret_cast<IO *>(p.y) + (int64_t)b * p.y_bs;
+    const bool ok = c < D;
+    v2f w[KMAX], acc[HS];
+    load_taps(reinterpret_cast<float *>(lds), p.weight, c0, D, K, pair, false, w);
+    stage_tile<IO>(lds, x, p.x_ts, t0 - p.pad_left, T, c0, D);
+    const v2f bias = (ok && p.bias) ? v2f{p.bias[c], p.bias[c + 1]} : v2f{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HS; ++j) acc[j] = bias;
+    __syncthreads();
+    corr16<IO>(lds, HS * hf, pair, w, acc);
+    if (!ok) return;
+#pragma unroll
+    for (int j = 0; j < HS; ++j) {
+        const int t = t0 + HS * hf + j;
+        if (t < T) st_pair<IO>(y + (int64_t)t * p.y_ts + c, acc[j]);
+    }
+}
+
+template <typename IO>
+__global__ __launch_bounds__(256) void dwconv_cl_bwd_tiled_kernel(const cm_dwconv_cl_args p, int nrun) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TILE = ROWS2 * CB * (int)sizeof(IO);
+    unsigned char *xt = lds, *gt = lds + TILE;
+    const int T = p.seqlen, K = p.ksize, D = p.dim;
+    const int b = blockIdx.x / nrun, run = blockIdx.x % nrun, c0 = blockIdx.y * CB;
+    const int pair = threadIdx.x & 127, hf = threadIdx.x >> 7, c = c0 + 2 * pair;
+    const IO *x = reinterpret_cast<const IO *>(p.x) + (int64_t)b * p.x_bs;
+    const IO *dy = reinterpret_cast<const IO *>(p.dy) + (int64_t)b * p.dy_bs;
+    IO *dx = reinterpret_cast<IO *>(p.dx) + (int64_t)b * p.dx_bs;
+    const bool ok = c < D;
+    const int padr = K - 1 - p.pad_left;                                  // halo in front of the dy tile
+    v2f dw[KMAX], db = {0.f, 0.f}, wr[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) dw[k] = v2f{0.f, 0.f};
+    load_taps(reinterpret_cast<float *>(lds), p.weight, c0, D, K, pair, true, wr);          // flipped taps for dx
+    for (int ti = 0; ti < RUN * TT / TT2; ++ti) {
+        const int t0 = run * RUN * TT + ti * TT2;
+        if (t0 >= T) break;
+        __syncthreads();                                                  // the previous tile's readers are done
+        stage_tile<IO>(xt, x, p.x_ts, t0 - p.pad_left, T, c0, D);
+        stage_tile<IO>(gt, dy, p.dy_ts, t0 - padr, T, c0, D);
+        __syncthreads();
+        {   // dx[s] = sum_k' w[K-1-k'] dy[s + k' - (K-1-pad_left)]
+            v2f acc[HS];
+#pragma unroll
+            for (int j = 0; j < HS; ++j) acc[j] = v2f{0.f, 0.f};
+            corr16<IO>(gt, HS * hf, pair, wr, acc);
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < HS; ++j) {
+                    const int t = t0 + HS * hf + j;
+                    if (t < T) st_pair<IO>(dx + (int64_t)t * p.dx_ts + c, acc[j]);
+                }
+            }
+        }
+        {   // dw[k] += sum_j dy[t0 + 16 hf + j] x[t0 + 16 hf + j + k - pad_left], by x row
+            v2f g[HS];
+#pragma unroll
+            for (int j = 0; j < HS; ++j) { g[j] = ld_pair<IO>(gt, HS * hf + j + padr, pair); db += g[j]; }
+#pragma unroll
+            for (int r = 0; r < HS + KMAX - 1; ++r) {
+                const v2f xv = ld_pair<IO>(xt, HS * hf + r, pair);
+#pragma unroll
+                for (int j = 0; j < HS; ++j) {
+                    const int k = r - j;
+                    if (k >= 0 && k < KMAX) dw[k] = __builtin_elementwise_fma(g[j], xv, dw[k]);
+                }
+            }
+        }
+    }
+    // the two step-halves of a channel pair meet through LDS; one partial row per (sequence, run)
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);
+    if (hf == 1) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) *reinterpret_cast<float2 *>(red + (pair * (KMAX + 1) + k) * 2) = make_float2(dw[k].x, dw[k].y);
+        *reinterpret_cast<float2 *>(red + (pair * (KMAX + 1) + KMAX) * 2) = make_float2(db.x, db.y);
+    }
+    __syncthreads();
+    if (hf == 0 && ok) {
+        float *part = p.partial + (int64_t)blockIdx.x * D * (KMAX + 1);
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k) {
+            const float2 o = *reinterpret_cast<const float2 *>(red + (pair * (KMAX + 1) + k) * 2);
+            const v2f m = k < KMAX ? dw[k] : db;
+            part[c * (KMAX + 1) + k] = m.x + o.x;
+            part[(c + 1) * (KMAX + 1) + k] = m.y + o.y;
+        }
+    }
+}
+
+inline bool tiled_ok(const cm_dwconv_cl_args &a) {
+    const int vec = a.io_dtype == CM_BF16 ? 8 : 4;
+    auto al = [&](const void *ptr, int64_t bs, int64_t ts) { return !ptr || (cm_aligned(ptr, 16) && bs % vec == 0 && ts % vec == 0); };
+    return a.dim % vec == 0 && al(a.x, a.x_bs, a.x_ts) && al(a.y, a.y_bs, a.y_ts) && al(a.dy, a.dy_bs, a.dy_ts) && al(a.dx, a.dx_bs, a.dx_ts);
+}
+
+template <typename K> int set_lds(K kern, size_t smem, const char *what) {
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) { cm_set_error("%s: LDS attribute failed: %s", what, hipGetErrorString(e)); return (int)e; }
+    }
+    return CM_OK;
+}
+
 // dweight[c][k] += sum over workgroups of partial[wg][c][k]; dbias[c] += ... (fixed order: deterministic).
 // A workgroup owns 32 consecutive (c, k) columns; its 8 thread groups walk the partial rows 8 apart with 8 loads in
 // flight each, then add up through LDS (one thread per column walking all rows serially took 120 us for 512 rows).
@@ -138,6 +318,19 @@ extern "C" int cm_dwconv_cl_fwd(const cm_dwconv_cl_args *args) {
     const int nrun = (a.seqlen + RUN * TT - 1) / (RUN * TT);
     CM_REQUIRE((int64_t)a.batch * nrun <= 2147483647LL, CM_EINVAL, "dwconv_cl_fwd: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+    if (tiled_ok(a)) {
+        const int ntile = (a.seqlen + TT2 - 1) / TT2;
+        const dim3 tg((unsigned)(a.batch * ntile), (unsigned)((a.dim + CB - 1) / CB));
+        const size_t smem = (size_t)ROWS2 * CB * (a.io_dtype == CM_BF16 ? 2 : 4);
+        if (a.io_dtype == CM_BF16) {
+            if (int rc = set_lds(dwconv_cl_fwd_tiled_kernel<cm_bf16>, smem, "dwconv_cl_fwd")) return rc;
+            hipLaunchKernelGGL(dwconv_cl_fwd_tiled_kernel<cm_bf16>, tg, dim3(256), smem, st, a, ntile);
+        } else {
+            if (int rc = set_lds(dwconv_cl_fwd_tiled_kernel<float>, smem, "dwconv_cl_fwd")) return rc;
+            hipLaunchKernelGGL(dwconv_cl_fwd_tiled_kernel<float>, tg, dim3(256), smem, st, a, ntile);
+        }
+        return cm_launch_status("cm_dwconv_cl_fwd(tiled)");
+    }
     dim3 grid((unsigned)(a.batch * nrun)), block(a.dim >= 256 ? 256 : ((a.dim + 63) / 64) * 64);
     if (a.io_dtype == CM_BF16) hipLaunchKernelGGL(dwconv_cl_fwd_kernel<cm_bf16>, grid, block, 0, st, a, nrun);
     else hipLaunchKernelGGL(dwconv_cl_fwd_kernel<float>, grid, block, 0, st, a, nrun);
@@ -154,7 +347,17 @@ extern "C" int cm_dwconv_cl_bwd(const cm_dwconv_cl_args *args) {
     CM_REQUIRE(nwg <= 2147483647LL, CM_EINVAL, "dwconv_cl_bwd: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     dim3 grid((unsigned)nwg), block(a.dim >= 256 ? 256 : ((a.dim + 63) / 64) * 64);
-    if (a.io_dtype == CM_BF16) hipLaunchKernelGGL(dwconv_cl_bwd_kernel<cm_bf16>, grid, block, 0, st, a, nrun);
+    if (tiled_ok(a)) {
+        const dim3 tg((unsigned)nwg, (unsigned)((a.dim + CB - 1) / CB));
+        const size_t smem = (size_t)2 * ROWS2 * CB * (a.io_dtype == CM_BF16 ? 2 : 4);
+        if (a.io_dtype == CM_BF16) {
+            if (int rc = set_lds(dwconv_cl_bwd_tiled_kernel<cm_bf16>, smem, "dwconv_cl_bwd")) return rc;
+            hipLaunchKernelGGL(dwconv_cl_bwd_tiled_kernel<cm_bf16>, tg, dim3(256), smem, st, a, nrun);
+        } else {
+            if (int rc = set_lds(dwconv_cl_bwd_tiled_kernel<float>, smem, "dwconv_cl_bwd")) return rc;
+            hipLaunchKernelGGL(dwconv_cl_bwd_tiled_kernel<float>, tg, dim3(256), smem, st, a, nrun);
+        }
+    } else if (a.io_dtype == CM_BF16) hipLaunchKernelGGL(dwconv_cl_bwd_kernel<cm_bf16>, grid, block, 0, st, a, nrun);
     else hipLaunchKernelGGL(dwconv_cl_bwd_kernel<float>, grid, block, 0, st, a, nrun);
     const int n = a.dim * (KMAX + 1);
     hipLaunchKernelGGL(dwconv_cl_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, a, (int)nwg);
