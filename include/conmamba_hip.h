@@ -360,6 +360,26 @@ typedef struct cm_conv_cl_bwd_args {
     int64_t workspace_floats;
 } cm_conv_cl_bwd_args;
 
+/* CTC loss + gradient (csrc/ctc.hip; replaces torch.nn.functional.ctc_loss behind speechbrain.nnet.losses.ctc_loss, reference
+ * train_CTC.py:405): log_probs (batch, T, V) fp32 contiguous (log-softmax outputs), targets (batch, S) int64 padded, lengths int32.
+ * nll[b] = negative log-likelihood (0 where no alignment exists: zero_infinity); grad (batch, T, V) fp32 = exp(lp) - posteriors
+ * for t < input_lengths[b], 0 elsewhere -- the gradient torch returns for a unit upstream gradient per utterance (the caller
+ * scales by grad_out / batch).  S <= 511.  Deterministic (fixed summation order). */
+typedef struct cm_ctc_args {
+    int32_t batch, T, V, S, blank, Sx_max;   /* Sx_max: set by the library (2 S + 1)                          */
+    const float   *log_probs;
+    const int64_t *targets;
+    const int32_t *input_lengths, *target_lengths;
+    float *nll, *grad;
+    float *workspace;                         /* cm_ctc_workspace_floats(batch, T, S) floats                    */
+    int64_t workspace_floats;
+    float *alpha, *beta;                      /* set by the library (views of workspace)                        */
+    void *stream;
+} cm_ctc_args;
+
+int64_t cm_ctc_workspace_floats(int32_t batch, int32_t T, int32_t S);
+int cm_ctc_loss(const cm_ctc_args *args);
+
 /* Element-wise stages of a feed-forward / convolution module's training step on (rows, dim) tensors (csrc/ffn_train.hip; the
  * reference leaves them to torch: reference modules/Conmamba.py:597-617):
  *   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))  [I/O dtype]      or, with res:  y = res + alpha * dropout(a + bias)  [fp32]

@@ -77,6 +77,14 @@ class ScanClArgs(C.Structure):
     ]
 
 
+class CtcArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("T", i32), ("V", i32), ("S", i32), ("blank", i32), ("Sx_max", i32),
+        ("log_probs", fp), ("targets", vp), ("input_lengths", vp), ("target_lengths", vp), ("nll", fp), ("grad", fp),
+        ("workspace", fp), ("workspace_floats", i64), ("alpha", fp), ("beta", fp), ("stream", vp),
+    ]
+
+
 class FfnElemArgs(C.Structure):
     _fields_ = [
         ("rows", i64), ("dim", i32), ("io_dtype", i32), ("act", i32), ("dy_f32", i32),
@@ -277,6 +285,8 @@ SYMBOLS = [
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_sum_leading", C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
+    ("cm_ctc_workspace_floats", C.c_int64, [i32, i32, i32]),
+    ("cm_ctc_loss", C.c_int, [C.POINTER(CtcArgs)]),
     ("cm_bias_act_dropout_bwd_workspace_floats", C.c_int64, [i64, i32]),
     ("cm_bias_act_dropout_fwd", C.c_int, [C.POINTER(FfnElemArgs)]),
     ("cm_bias_act_dropout_bwd", C.c_int, [C.POINTER(FfnElemArgs)]),

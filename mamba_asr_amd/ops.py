@@ -533,6 +533,47 @@ def bias_glu_bwd(dy, a, bias):
     return da, dbias
 
 
+def ctc_supported(log_probs, targets) -> bool:
+    return log_probs.is_cuda and log_probs.dim() == 3 and targets.dim() == 2 and targets.shape[1] <= 511 and log_probs.shape[2] > 1
+
+
+def ctc_loss_grad(log_probs, targets, input_lengths, target_lengths, blank=0):
+    """log_probs (batch, T, V) -> (nll (batch) fp32, grad (batch, T, V) fp32) (cm_ctc_loss): per-utterance negative log-likelihood
+    (0 where no alignment exists) and its gradient w.r.t. log_probs; lengths are integer tensors."""
+    _dev_check(log_probs, targets, input_lengths, target_lengths)
+    lp = log_probs.detach().float().contiguous()
+    b, t, v = lp.shape
+    tg = targets.detach().to(torch.int64).contiguous()
+    il, tl = input_lengths.detach().to(torch.int32).contiguous(), target_lengths.detach().to(torch.int32).contiguous()
+    s = tg.shape[1]
+    nll = torch.empty((b,), dtype=torch.float32, device=lp.device)
+    grad = torch.empty_like(lp)
+    nws = int(N.lib().cm_ctc_workspace_floats(b, t, s))
+    ws = torch.empty((nws,), dtype=torch.float32, device=lp.device)
+    a = N.CtcArgs()
+    a.batch, a.T, a.V, a.S, a.blank = b, t, v, s, int(blank)
+    a.log_probs, a.targets, a.input_lengths, a.target_lengths, a.nll, a.grad = _ptr(lp), _ptr(tg), _ptr(il), _ptr(tl), _ptr(nll), _ptr(grad)
+    a.workspace, a.workspace_floats, a.stream = _ptr(ws), nws, _stream()
+    _launch("cm_ctc_loss", N.lib().cm_ctc_loss, a, units=b * t)
+    return nll, grad
+
+
+class CtcLossFn(torch.autograd.Function):
+    """sum over the batch of the per-utterance CTC negative log-likelihoods (zero_infinity), gradient from the same call."""
+
+    @staticmethod
+    def forward(ctx, log_probs, targets, input_lengths, target_lengths, blank):
+        nll, grad = ctc_loss_grad(log_probs, targets, input_lengths, target_lengths, blank)
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = log_probs.dtype
+        return nll.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).to(ctx.in_dtype), None, None, None, None
+
+
 def sum_leading(t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     """t (batch, ...) -> sum over the leading axis with fp32 accumulation in a fixed order (cm_sum_leading): folds per-utterance
     weight-gradient products; output in ``out_dtype`` (fp32 = a parameter's gradient dtype, no cast afterwards)."""

@@ -486,13 +486,21 @@ class ConvolutionFrontEnd(nn.Module):
         return x
 
 
+# CTC loss + gradient on cm_ctc_loss (csrc/ctc.hip) for GPU tensors; CM_NATIVE_CTC=0 = torch.nn.functional.ctc_loss
+USE_NATIVE_CTC = os.environ.get("CM_NATIVE_CTC", "1") == "1"
+
+
 def ctc_loss(log_probs, targets, input_lens, target_lens, blank_index, reduction="mean"):
     """speechbrain.nnet.losses.ctc_loss: relative lengths -> F.ctc_loss(sum, zero_infinity); 'batchmean' = / batch."""
     t = log_probs.shape[1]
     il = torch.round(input_lens * t).int()
     tl = torch.round(target_lens * targets.shape[1]).int()
-    loss = F.ctc_loss(log_probs.transpose(0, 1).float(), targets, il, tl, blank_index, reduction="sum",
-                      zero_infinity=True)
+    from . import ops
+    if USE_NATIVE_CTC and ops.ctc_supported(log_probs, targets):
+        # cm_ctc_loss: alpha and beta concurrently, deterministic gradient (torch: three launches, atomics in the backward)
+        loss = ops.CtcLossFn.apply(log_probs, targets, il, tl, blank_index)
+    else:
+        loss = F.ctc_loss(log_probs.transpose(0, 1).float(), targets, il, tl, blank_index, reduction="sum", zero_infinity=True)
     if reduction == "batchmean":
         return loss / targets.shape[0]
     if reduction == "mean":

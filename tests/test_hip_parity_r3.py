@@ -151,9 +151,9 @@ def _same_grads(a, b, names, cnn_tol=1e-5):
 
 
 def test_training_step_gradients_are_bit_reproducible():
-    """Everything between the CNN front end (vendor conv2d backward) and the CTC loss's own backward (torch's kernel
-    accumulates with atomics) is deterministic: with the gradient of the log-probabilities held fixed, two backward passes
-    give bit-identical gradients for every encoder / projection / head parameter."""
+    """Everything behind the CNN front end (vendor conv2d backward) is deterministic: with the gradient of the log-probabilities
+    held fixed, and with the real CTC objective (cm_ctc_loss; torch's CTC backward accumulates with atomics), two passes give
+    bit-identical gradients for every encoder / projection / head parameter."""
     cfg, model, wavs, lens, tokens, tok_lens = _train_case(batch=2, frames=200)
     runs = []
     g = None
@@ -168,6 +168,13 @@ def test_training_step_gradients_are_bit_reproducible():
     names = list(runs[0])
     assert _same_grads([runs[0][k] for k in names], [runs[1][k] for k in names], names)
     assert sum(not k.startswith("CNN.") for k in names) >= 90
+    # round 3: with the CTC loss on cm_ctc_loss (fixed-order posterior sums) the real objective is reproducible as well
+    full = []
+    for _ in range(2):
+        loss, grads, _ = _gpu_loss_and_grads(model, wavs, lens, tokens, tok_lens)
+        full.append((loss, grads))
+    assert torch.equal(full[0][0], full[1][0])
+    assert _same_grads([full[0][1][k] for k in names], [full[1][1][k] for k in names], names)
 
 
 # ----------------------------------------------------------------------------------------------------------
