@@ -264,7 +264,11 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
                 const f32x4 Bv = *reinterpret_cast<const f32x4 *>(xb + j * XSB);
                 const f32x2 d2 = {dw.x, dw.x}, w2 = {dw.y, dw.y};
                 const f32x2 x01 = d2 * Ap01, x23 = d2 * Ap23;
+#if defined(CM_BWD_ABL) && CM_BWD_ABL == 3
+                const f32x2 a01 = x01 * 0.5f + 1.0f, a23 = x23 * 0.5f + 1.0f;           // timing ablation: no exponentials
+#else
                 const f32x2 a01 = f32x2{cm_exp2(x01.x), cm_exp2(x01.y)}, a23 = f32x2{cm_exp2(x23.x), cm_exp2(x23.y)};
+#endif
                 h01 = __builtin_elementwise_fma(a01, h01, w2 * f32x2{Bv[0], Bv[1]});
                 h23 = __builtin_elementwise_fma(a23, h23, w2 * f32x2{Bv[2], Bv[3]});
                 a01s[si] = a01, a23s[si] = a23, h01s[si] = h01, h23s[si] = h23;
@@ -292,12 +296,30 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
                 sa = __builtin_elementwise_fma(r23, Ap23, sa);
                 lam01 = l01 * a01s[si];
                 lam23 = l23 * a23s[si];
-                // sums over the 16 states of the channel: in-lane, then the quad
-                const float sbs = cm_group_sum<4>(sb.x + sb.y), sas = cm_group_sum<4>(sa.x + sa.y);
+                // sums over the 16 states of the channel (in-lane, then the quad: 2 DPP adds each) and over the 4 channels of the row
+                // (row_shr:8, row_shr:4: valid in lanes 12..15), as ONE block of v_add_f32 with the DPP operand: through the
+                // builtin the compiler emitted v_mov_b32_dpp + packed adds + hazard nops (704 moves, 175 nops in the kernel), 6-8
+                // issue cycles per sum instead of 4.  One s_nop covers the VALU-write -> DPP-read hazard of every input; later
+                // reads are >= 2 instructions behind their writes.
+                float sbs = sb.x + sb.y, sas = sa.x + sa.y;
+                float b0 = aB01.x, b1 = aB01.y, b2 = aB23.x, b3 = aB23.y, c0_ = aC01.x, c1 = aC01.y, c2 = aC23.x, c3 = aC23.y;
+#if !defined(CM_BWD_ABL) || CM_BWD_ABL != 1
+#define CM_DPP_ADD(r, ctl) "v_add_f32_dpp " r ", " r ", " r " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                asm volatile("s_nop 1\n\t"
+                             CM_DPP_ADD("%0", "quad_perm:[1,0,3,2]") CM_DPP_ADD("%1", "quad_perm:[1,0,3,2]")
+                             CM_DPP_ADD("%2", "row_shr:8") CM_DPP_ADD("%3", "row_shr:8") CM_DPP_ADD("%4", "row_shr:8") CM_DPP_ADD("%5", "row_shr:8")
+                             CM_DPP_ADD("%6", "row_shr:8") CM_DPP_ADD("%7", "row_shr:8") CM_DPP_ADD("%8", "row_shr:8") CM_DPP_ADD("%9", "row_shr:8")
+                             CM_DPP_ADD("%0", "quad_perm:[2,3,0,1]") CM_DPP_ADD("%1", "quad_perm:[2,3,0,1]")
+                             CM_DPP_ADD("%2", "row_shr:4") CM_DPP_ADD("%3", "row_shr:4") CM_DPP_ADD("%4", "row_shr:4") CM_DPP_ADD("%5", "row_shr:4")
+                             CM_DPP_ADD("%6", "row_shr:4") CM_DPP_ADD("%7", "row_shr:4") CM_DPP_ADD("%8", "row_shr:4") CM_DPP_ADD("%9", "row_shr:4")
+                             : "+v"(sbs), "+v"(sas), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0_), "+v"(c1), "+v"(c2), "+v"(c3));
+#undef CM_DPP_ADD
+#else
+                sbs = cm_group_sum<4>(sbs), sas = cm_group_sum<4>(sas);
+#endif
                 if (q == 0) *reinterpret_cast<float2 *>(pout + (4 * g + cl) * POUT + 2 * j) = make_float2(sbs, sas);
-                // sums over the 4 channels of the row
-                const f32x4 rB = {row_quad_channel_sum(aB01.x), row_quad_channel_sum(aB01.y), row_quad_channel_sum(aB23.x), row_quad_channel_sum(aB23.y)};
-                const f32x4 rC = {row_quad_channel_sum(aC01.x), row_quad_channel_sum(aC01.y), row_quad_channel_sum(aC23.x), row_quad_channel_sum(aC23.y)};
+#if !defined(CM_BWD_ABL) || CM_BWD_ABL != 1
+                const f32x4 rB = {b0, b1, b2, b3}, rC = {c0_, c1, c2, c3};
                 if (cl == 3) {
                     *reinterpret_cast<f32x4 *>(redw + (j & 3) * 32) = rB;
                     *reinterpret_cast<f32x4 *>(redw + (j & 3) * 32 + 16) = rC;
@@ -310,6 +332,9 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
                     for (int gg = 1; gg < 4; ++gg) v += *reinterpret_cast<const f32x2 *>(red + gg * 128 + jj * 32 + col);
                     *reinterpret_cast<f32x2 *>(xw + (w * TB + (j & ~3) + jj) * RW + DTR + col) = v;
                 }
+#else
+                asm volatile("" ::"v"(aB01), "v"(aB23), "v"(aC01), "v"(aC23));          // timing ablation: no dB / dC reduction
+#endif
                 asm volatile("" : "+v"(lam01), "+v"(lam23), "+v"(dA01), "+v"(dA23));
             }
         }
@@ -336,6 +361,7 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
         quad_io<IO>::store(dur, w_u, duv);
         quad_io<IO>::store(dzr, w_z, dzv);
         w_u += sw_u, w_z += sw_z;
+#if !defined(CM_BWD_ABL) || CM_BWD_ABL != 2
         // d dt[t][r] = sum over the wave's channels of ddelta_raw[c][t] W_dt[c][r]   (A: lane (m = t, k = channel), B: lane (n = r, k = channel))
         // ddt_weight[c][r] += sum_t ddelta_raw[c][t] dt[t][r]                        (A: lane (m = c, k = t) from the transposition patch)
         if constexpr (S == 2) {
@@ -362,10 +388,12 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
             for (int i = 0; i < 4; ++i)
                 dWacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s16 * TRS + 4 * g + i], xt[(4 * g + i) * XSB + s16], dWacc[0], 0, 0, 0);
         }
+#endif
 
         tb += BDIR * TB;
         if (more) commit(x_nxt);
         cm_lds_barrier();
+#if !defined(CM_BWD_ABL) || CM_BWD_ABL != 4
         // ================= the workgroup's partial dxdbl rows of this block: sum of the 4 waves -> workspace
         {
             const int tbk = tb - BDIR * TB;                          // this block's base step
@@ -379,6 +407,7 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
             }
         }
         cm_lds_barrier();                                            // the cross-wave tile is rewritten during the next block
+#endif
         cu = nu, cz = nz, cg = ng, cy = ny, ch[0] = nh[0], ch[1] = nh[1];
         const int x_old = x_cur;
         x_cur = x_nxt, x_nxt = x_old;
