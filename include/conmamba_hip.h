@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 7
+#define CM_ABI_VERSION 8
 
 /* error codes */
 #define CM_OK            0
@@ -309,6 +309,9 @@ typedef struct cm_scan_cl_bwd_args {
     int32_t ndir;            /* 1 or 2                                                       */
     const void *z;           /* (batch, seqlen, dim), required                               */
     int64_t z_bs, z_ts;
+    int32_t time_chunks;     /* 0: automatic (launches under 512 workgroups are cut along time: adjoint summaries per chunk,
+                                a carry fold, then the full pass per chunk from its carried-in adjoint); 1: never; n: n chunks */
+    int32_t reserved0;
     cm_scan_cl_bwd_dir dir[2];
     void   *stream;
     void   *workspace;       /* cm_scan_cl_bwd_workspace_bytes(args) bytes, 16-byte aligned  */
@@ -316,6 +319,8 @@ typedef struct cm_scan_cl_bwd_args {
 } cm_scan_cl_bwd_args;
 
 int64_t cm_scan_cl_bwd_workspace_bytes(const cm_scan_cl_bwd_args *args);
+/* the chunk count time_chunks = 0 resolves to */
+int cm_scan_cl_bwd_auto_chunks(int batch, int seqlen, int dim, int ndir);
 int cm_scan_cl_bwd(const cm_scan_cl_bwd_args *args);
 
 /* ---------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -118,7 +118,7 @@ class ScanClBwdDir(C.Structure):
 class ScanClBwdArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32), ("io_dtype", i32), ("ndir", i32),
-        ("z", vp), ("z_bs", i64), ("z_ts", i64),
+        ("z", vp), ("z_bs", i64), ("z_ts", i64), ("time_chunks", i32), ("reserved0", i32),
         ("dir", ScanClBwdDir * 2),
         ("stream", vp), ("workspace", vp), ("workspace_bytes", i64),
     ]
@@ -282,6 +282,7 @@ SYMBOLS = [
     ("cm_scan_cl_fwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClArgs)]),
     ("cm_scan_cl_fwd_auto_chunks", i32, [i32, i32, i32, i32]),
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
+    ("cm_scan_cl_bwd_auto_chunks", C.c_int, [C.c_int] * 4),
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_sum_leading", C.c_int, [vp, vp, i32, i64, i32, i32, vp]),

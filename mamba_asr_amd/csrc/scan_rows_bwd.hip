@@ -41,10 +41,18 @@ template <int DTR> struct bwd_lds {
     static constexpr int kBytes = kXw + 4 * TB * RW * 4;
 };
 
+// Time chunks (launches of fewer than 512 workgroups leave CUs idle: config 5 trains 4 x 160 s per GPU = 128 workgroups at
+// E = 1024): the adjoint lambda_t = C_t g_t + a_{t+1} lambda_{t+1} is linear in what enters a chunk from later steps,
+// L_out = P L_in + E with P = prod a_t over the chunk and E the carry the chunk produces from L_in = 0.  Pass 1 (SUM) runs only
+// the adjoint of every chunk from zero (no state recompute, no outputs: a_t, C_t g_t), rows_bwd_carry_kernel folds (P, E) against
+// the scan, pass 2 is the full kernel per chunk started from its L_in; the forward's checkpoints give every chunk its states.
 struct bwd_plan {
     int nx;                    // 64-channel groups
+    int chunks, chunk_len;     // chunk_len: multiple of TB
+    int pass;                  // 0 unchunked, 1 summaries, 2 full from carried-in adjoints
     float *wsx;                // (ndir, nx, batch, seqlen, RW) fp32 partial dxdbl rows
-    float *wsp;                // (ndir, batch, dim, 16 + P + 4) fp32 per-sequence parameter gradients
+    float *wsp;                // (ndir, batch, chunks, dim, 16 + P + 4) fp32 per-(sequence, chunk) parameter gradients
+    float *lin, *le, *lp;      // (ndir, batch, chunks, dim, 16) fp32: adjoint entering a chunk, its E, its P
 };
 
 __device__ __forceinline__ u32x2 ld8(const __amdgpu_buffer_rsrc_t r, int off) {
@@ -77,9 +85,12 @@ __device__ __forceinline__ float row_quad_channel_sum(float v) {
     return v;
 }
 
-template <typename IO, bool REV, int DTR>
+// Runs steps [t_lo, t_lo + T) of sequence b.  lam_in: (dim, 16) adjoint carry entering the range from later scan steps, or NULL.
+// SUM: summary pass -- only the adjoint recurrence; writes e_out (its carry from zero) and p_out (decay product), (dim, 16) each.
+template <typename IO, bool REV, int DTR, bool SUM>
 __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, const cm_scan_cl_bwd_dir &d, unsigned char *lds,
-                                              const int cx, const int b, float *wsx, float *wsp) {
+                                              const int cx, const int b, const int t_lo, const int T, float *wsx, float *wsp,
+                                              const float *lam_in, float *e_out, float *p_out) {
     using L = bwd_lds<DTR>;
     constexpr int S = (int)sizeof(IO);
     constexpr int VEC = cm_elem<IO>::kVec;
@@ -92,8 +103,8 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4, q = lane & 3, cl = (lane >> 2) & 3;
-    const int E = p.dim, T = p.seqlen, c0 = cx * 64;
-    const int nblk = (T + TB - 1) / TB;
+    const int E = p.dim, c0 = cx * 64;
+    const int nblk = (T + TB - 1) / TB, nblk_seq = (p.seqlen + TB - 1) / TB;
     constexpr int DIR = REV ? -1 : 1;
     // owner layout: step s16 of the block, channels co .. co + 3;  recurrence layout: channel cr, states 4q .. 4q + 3
     const int co = c0 + 16 * w + 4 * g, cr = co + cl;
@@ -102,7 +113,7 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
     const int u_ts = (int)d.u_ts, z_ts = (int)p.z_ts, g_ts = (int)d.dout_ts, y_ts = (int)d.ypre_ts, x_ts = (int)d.xdbl_ts;
     const int du_ts = (int)d.du_ts, dz_ts = (int)d.dz_ts;
     auto rs = [&](const void *base, int64_t bs, int ts, int width) {
-        return make_rsrc(reinterpret_cast<const IO *>(base) + (int64_t)b * bs, ((int64_t)(T - 1) * ts + width) * S);
+        return make_rsrc(reinterpret_cast<const IO *>(base) + (int64_t)b * bs + (int64_t)t_lo * ts, ((int64_t)(T - 1) * ts + width) * S);
     };
     const __amdgpu_buffer_rsrc_t ur = rs(d.u, d.u_bs, u_ts, E), zr = rs(p.z, p.z_bs, z_ts, E), gr = rs(d.dout, d.dout_bs, g_ts, E),
                                  yr = rs(d.ypre, d.ypre_bs, y_ts, E), xr = rs(d.xdbl, d.xdbl_bs, x_ts, RW),
@@ -134,18 +145,22 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
     const int s_u = ok ? BDIR * TB * u_ts * S : 0, s_z = ok ? BDIR * TB * z_ts * S : 0, s_g = ok ? BDIR * TB * g_ts * S : 0,
               s_y = ok ? BDIR * TB * y_ts * S : 0, sw_u = ok ? BDIR * TB * du_ts * S : 0, sw_z = ok ? BDIR * TB * dz_ts * S : 0;
     // (batch, 2 nblk, dim, 16): entry state of every half block of 8 steps [8 m, 8 m + 8), in scan order
-    const float *ckp = d.ckpt + (((int64_t)b * 2 * nblk + 2 * (tbb0 / TB)) * E + crc) * 16 + 4 * q;
+    const float *ckp = d.ckpt + (((int64_t)b * 2 * nblk_seq + 2 * ((t_lo + tbb0) / TB)) * E + crc) * 16 + 4 * q;
     const int64_t ck_step = (int64_t)BDIR * 2 * E * 16;
     quad_io<IO> nu, nz, ng, ny;
     float4 nh[2];                                                    // [time half of the block]
     auto issue = [&]() {
         rx = __builtin_amdgcn_raw_buffer_load_b128(xr, x_off, 0, 0);
         x_off += x_step;
-        nu.load(ur, r_u), nz.load(zr, r_z), ng.load(gr, r_g), ny.load(yr, r_y);
-        r_u += s_u, r_z += s_z, r_g += s_g, r_y += s_y;
-        nh[0] = *reinterpret_cast<const float4 *>(ckp);
-        nh[1] = *reinterpret_cast<const float4 *>(ckp + (int64_t)E * 16);
-        ckp += ck_step;
+        nz.load(zr, r_z), ng.load(gr, r_g);
+        r_z += s_z, r_g += s_g;
+        if constexpr (!SUM) {
+            nu.load(ur, r_u), ny.load(yr, r_y);
+            r_u += s_u, r_y += s_y;
+            nh[0] = *reinterpret_cast<const float4 *>(ckp);
+            nh[1] = *reinterpret_cast<const float4 *>(ckp + (int64_t)E * 16);
+            ckp += ck_step;
+        }
     };
     auto commit = [&](const int buf_x) {
         if (x_thread) {
@@ -204,6 +219,11 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
 
     // ---- state carried over the whole sequence
     f32x2 lam01 = {0.f, 0.f}, lam23 = {0.f, 0.f};                    // adjoint state a_{t+1} lambda_{t+1}
+    if (lam_in && ok) {
+        const float4 l4 = *reinterpret_cast<const float4 *>(lam_in + (int64_t)cr * 16 + 4 * q);
+        lam01 = f32x2{l4.x, l4.y}, lam23 = f32x2{l4.z, l4.w};
+    }
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};                            // SUM: delta' of the owned (step, channels) over the chunk
     f32x2 dA01 = {0.f, 0.f}, dA23 = {0.f, 0.f};
     float dDacc[4] = {0.f, 0.f, 0.f, 0.f}, dbacc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 dWacc[DTR / 16];                                           // ddt_weight tile: lane (feature lane%16, gq) reg i <-> channel 4 gq + i of the wave
@@ -215,6 +235,7 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
     commit(x_cur);
     quad_io<IO> cu = nu, cz = nz, cg = ng, cy = ny;
     float4 ch[2] = {nh[0], nh[1]};
+    (void)cu, (void)cy, (void)ch;
     __syncthreads();
     int tb = tbb0;
     for (int k = 0; k < nblk; ++k) {
@@ -239,10 +260,34 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
             const float pre = acc[i] + bias[i];
             float dv = softplus_rows(pre);
             dv = (valid && ok) ? dv : 0.f;                           // padded steps / channels: a = 1, b = 0, nothing flows
-            const float uv = cu.get(i), zv = cz.get(i), gv = cg.get(i);
+            const float uv = SUM ? 0.f : cu.get(i), zv = cz.get(i), gv = cg.get(i);
             const float gzv = (valid && ok) ? gv * zv * cm_sigmoid(zv) : 0.f;
+            if constexpr (SUM) dsum[i] += dv;
             // the 4th slot keeps the pre-activation for the epilogue's softplus' (re-read there instead of living in registers)
             *reinterpret_cast<f32x4 *>(pin + (4 * g + i) * PIN + 4 * s16) = f32x4{dv, dv * uv, gzv, pre};
+        }
+        if constexpr (SUM) {
+            // summary pass: the adjoint alone.  lambda_t = C_t g_t + carry;  carry = a_t lambda_t
+            const float *pl = pin + (4 * g + cl) * PIN;
+            const float *xb = xt + BOFF + 4 * q;
+#pragma unroll
+            for (int sp = TB - 1; sp >= 0; --sp) {
+                const int j = REV ? TB - 1 - sp : sp;
+                const f32x4 dwg = *reinterpret_cast<const f32x4 *>(pl + 4 * j);
+                const f32x4 Cv = *reinterpret_cast<const f32x4 *>(xb + j * XSB + 16);
+                const f32x2 d2 = {dwg[0], dwg[0]}, g2 = {dwg[2], dwg[2]};
+                const f32x2 x01 = d2 * Ap01, x23 = d2 * Ap23;
+                const f32x2 a01 = f32x2{cm_exp2(x01.x), cm_exp2(x01.y)}, a23 = f32x2{cm_exp2(x23.x), cm_exp2(x23.y)};
+                lam01 = __builtin_elementwise_fma(f32x2{Cv[0], Cv[1]}, g2, lam01) * a01;
+                lam23 = __builtin_elementwise_fma(f32x2{Cv[2], Cv[3]}, g2, lam23) * a23;
+            }
+            tb += BDIR * TB;
+            if (more) commit(x_nxt);
+            cm_lds_barrier();
+            cz = nz, cg = ng;
+            const int x_old = x_cur;
+            x_cur = x_nxt, x_nxt = x_old;
+            continue;
         }
 
         // ================= recurrence phase
@@ -402,7 +447,7 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
                 const int o = tid + 256 * r;
                 if (o < TB * RW) {
                     const float v = (xw[o] + xw[TB * RW + o]) + (xw[2 * TB * RW + o] + xw[3 * TB * RW + o]);
-                    if (tbk + o / RW < T) wsx[(int64_t)tbk * RW + o] = v;
+                    if (tbk + o / RW < T) wsx[(int64_t)(t_lo + tbk) * RW + o] = v;
                 }
             }
         }
@@ -413,6 +458,22 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
         x_cur = x_nxt, x_nxt = x_old;
     }
 
+    if constexpr (SUM) {
+        // E = the carry this chunk hands on from a zero entry; P = exp(A sum of delta') per (channel, state)
+        float *sl = tr;                                              // 16 floats per wave: sum of delta' per channel of the wave
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sd = cm_group_sum<16>(dsum[i]);
+            if (s16 == 0) sl[4 * g + i] = sd;
+        }
+        const float sc = sl[4 * g + cl];                             // in-order LDS within the wave
+        if (ok) {
+            *reinterpret_cast<float4 *>(e_out + (int64_t)cr * 16 + 4 * q) = make_float4(lam01.x, lam01.y, lam23.x, lam23.y);
+            *reinterpret_cast<float4 *>(p_out + (int64_t)cr * 16 + 4 * q) =
+                make_float4(cm_exp2(Ap01.x * sc), cm_exp2(Ap01.y * sc), cm_exp2(Ap23.x * sc), cm_exp2(Ap23.y * sc));
+        }
+        return;
+    }
     // ---- per-sequence parameter gradients -> workspace (summed over the batch by the reduce kernel)
     float *pp = wsp + (int64_t)crc * NP;
     if (ok) *reinterpret_cast<float4 *>(pp + 4 * q) = make_float4(dA01.x, dA01.y, dA23.x, dA23.y);
@@ -432,19 +493,41 @@ __device__ __forceinline__ void scan_rows_bwd(const cm_scan_cl_bwd_args &p, cons
 }
 
 // bf16: two workgroups per CU (256 VGPRs); the fp32 instantiation (parity tests) carries twice the row registers: one per CU
-template <typename IO, int DTR>
+template <typename IO, int DTR, bool SUM>
 __global__ __launch_bounds__(256, sizeof(IO) == 2 ? 2 : 1) void scan_rows_bwd_kernel(const cm_scan_cl_bwd_args p, const bwd_plan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int RW = DTR + 32, NP = 16 + DTR + 4;
-    const int total = gridDim.x, nx = pl.nx;
+    const int total = gridDim.x, nx = pl.nx, nbk = p.batch * pl.chunks;
     int id = blockIdx.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);   // workgroups of one (sequence, direction) on one XCD
-    const int cx = id % nx, b = (id / nx) % p.batch, z = id / (nx * p.batch);
+    const int cx = id % nx, bk = (id / nx) % nbk, z = id / (nx * nbk);
+    const int b = bk / pl.chunks, k = bk % pl.chunks;
     const cm_scan_cl_bwd_dir &d = p.dir[z];
+    const int t_lo = k * pl.chunk_len, T = min(p.seqlen - t_lo, pl.chunk_len);
     float *wsx = pl.wsx + (((int64_t)z * nx + cx) * p.batch + b) * p.seqlen * RW;
-    float *wsp = pl.wsp + ((int64_t)z * p.batch + b) * p.dim * NP;
-    if (d.reverse_time) scan_rows_bwd<IO, true, DTR>(p, d, lds, cx, b, wsx, wsp);
-    else scan_rows_bwd<IO, false, DTR>(p, d, lds, cx, b, wsx, wsp);
+    const int64_t slot = ((int64_t)z * p.batch + b) * pl.chunks + k;
+    float *wsp = pl.wsp + slot * p.dim * NP;
+    const float *lam_in = pl.pass == 2 ? pl.lin + slot * p.dim * 16 : nullptr;
+    float *e_out = SUM ? pl.le + slot * p.dim * 16 : nullptr, *p_out = SUM ? pl.lp + slot * p.dim * 16 : nullptr;
+    if (d.reverse_time) scan_rows_bwd<IO, true, DTR, SUM>(p, d, lds, cx, b, t_lo, T, wsx, wsp, lam_in, e_out, p_out);
+    else scan_rows_bwd<IO, false, DTR, SUM>(p, d, lds, cx, b, t_lo, T, wsx, wsp, lam_in, e_out, p_out);
+}
+
+// adjoint entering every chunk, folded against the scan: one thread per (direction, sequence, channel, state quad)
+__global__ __launch_bounds__(256) void rows_bwd_carry_kernel(const cm_scan_cl_bwd_args p, const bwd_plan pl) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int E = p.dim, C = pl.chunks;
+    if (idx >= (int64_t)p.ndir * p.batch * E * 4) return;
+    const int q = (int)(idx & 3), c = (int)((idx >> 2) % E), b = (int)((idx >> 2) / E % p.batch), z = (int)((idx >> 2) / E / p.batch);
+    const bool rev = p.dir[z].reverse_time != 0;
+    float4 Lc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < C; ++i) {
+        const int k = rev ? i : C - 1 - i;                           // the chunk the scan ran last comes first
+        const int64_t off = ((((int64_t)z * p.batch + b) * C + k) * E + c) * 16 + 4 * q;
+        *reinterpret_cast<float4 *>(pl.lin + off) = Lc;
+        const float4 a = *reinterpret_cast<const float4 *>(pl.lp + off), e = *reinterpret_cast<const float4 *>(pl.le + off);
+        Lc = make_float4(fmaf(a.x, Lc.x, e.x), fmaf(a.y, Lc.y, e.y), fmaf(a.z, Lc.z, e.z), fmaf(a.w, Lc.w, e.w));
+    }
 }
 
 // fixed-order second pass: dxdbl rows = sum over the channel-group workgroups (stored in the I/O dtype); parameter gradients =
@@ -470,9 +553,10 @@ __global__ __launch_bounds__(256) void scan_rows_bwd_reduce_kernel(const cm_scan
             const int z = (int)(j / ((int64_t)p.dim * NP));
             const int64_t cj = j - (int64_t)z * p.dim * NP;          // (channel, slot)
             const int c = (int)(cj / NP), slot = (int)(cj % NP);
-            const float *src = pl.wsp + (int64_t)z * p.batch * p.dim * NP + cj;
+            const int64_t nslab = (int64_t)p.batch * pl.chunks;
+            const float *src = pl.wsp + (int64_t)z * nslab * p.dim * NP + cj;
             float acc = 0.f;
-            for (int b = 0; b < p.batch; ++b) acc += src[(int64_t)b * p.dim * NP];
+            for (int64_t b = 0; b < nslab; ++b) acc += src[b * p.dim * NP];
             const cm_scan_cl_bwd_dir &d = p.dir[z];
             if (slot < 16) d.dA[(int64_t)c * 16 + slot] += acc;
             else if (slot < 16 + DTR) d.ddt_weight[(int64_t)c * DTR + slot - 16] += acc;
@@ -482,17 +566,41 @@ __global__ __launch_bounds__(256) void scan_rows_bwd_reduce_kernel(const cm_scan
     }
 }
 
+inline int bwd_chunk_len(int seqlen, int chunks) { return ((seqlen + chunks - 1) / chunks + TB - 1) / TB * TB; }
+
+// chunk count for a launch: below 512 workgroups (two per CU) the sequences are cut so that about 1024 run, chunks >= 128 steps
+inline int bwd_auto_chunks(int batch, int seqlen, int dim, int ndir, int want) {
+    if (want >= 1) {
+        if (want == 1 || seqlen < 2 * TB) return 1;
+        const int len = bwd_chunk_len(seqlen, want);
+        return (seqlen + len - 1) / len;
+    }
+    const long wgs = (long)((dim + 63) / 64) * batch * ndir;
+    if (wgs >= 512) return 1;
+    long c = (1024 + wgs - 1) / wgs;
+    if (c > seqlen / 128) c = seqlen / 128;
+    if (c < 2) return 1;
+    const int len = bwd_chunk_len(seqlen, (int)c);
+    return (seqlen + len - 1) / len;
+}
+
 template <typename IO, int DTR>
 int launch_bwd(const cm_scan_cl_bwd_args &a) {
     constexpr int RW = DTR + 32, NP = 16 + DTR + 4;
     bwd_plan pl{};
     pl.nx = (a.dim + 63) / 64;
+    pl.chunks = bwd_auto_chunks(a.batch, a.seqlen, a.dim, a.ndir, a.time_chunks);
+    pl.chunk_len = pl.chunks > 1 ? bwd_chunk_len(a.seqlen, pl.chunks) : (a.seqlen + TB - 1) / TB * TB;
     pl.wsx = reinterpret_cast<float *>(a.workspace);
     pl.wsp = pl.wsx + (int64_t)a.ndir * pl.nx * a.batch * a.seqlen * RW;
+    pl.lin = pl.wsp + (int64_t)a.ndir * a.batch * pl.chunks * a.dim * NP;
+    pl.le = pl.lin + (int64_t)a.ndir * a.batch * pl.chunks * a.dim * 16;
+    pl.lp = pl.le + (int64_t)a.ndir * a.batch * pl.chunks * a.dim * 16;
     const size_t smem = bwd_lds<DTR>::kBytes;
     static bool attr_done = false;
     if (!attr_done && smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_rows_bwd_kernel<IO, DTR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_rows_bwd_kernel<IO, DTR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_rows_bwd_kernel<IO, DTR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             cm_set_error("scan_cl_bwd: hipFuncSetAttribute(%zu B LDS) failed: %s", smem, hipGetErrorString(e));
             return (int)e;
@@ -500,8 +608,17 @@ int launch_bwd(const cm_scan_cl_bwd_args &a) {
         attr_done = true;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
-    const long total = (long)pl.nx * a.batch * a.ndir;
-    hipLaunchKernelGGL((scan_rows_bwd_kernel<IO, DTR>), dim3((unsigned)total), dim3(256), smem, st, a, pl);
+    const long total = (long)pl.nx * a.batch * pl.chunks * a.ndir;
+    if (pl.chunks > 1) {
+        pl.pass = 1;
+        hipLaunchKernelGGL((scan_rows_bwd_kernel<IO, DTR, true>), dim3((unsigned)total), dim3(256), smem, st, a, pl);
+        if (int rc = cm_launch_status("cm_scan_cl_bwd(chunk summaries)")) return rc;
+        const long nthr = (long)a.ndir * a.batch * a.dim * 4;
+        hipLaunchKernelGGL(rows_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a, pl);
+        if (int rc = cm_launch_status("cm_scan_cl_bwd(carry)")) return rc;
+        pl.pass = 2;
+    }
+    hipLaunchKernelGGL((scan_rows_bwd_kernel<IO, DTR, false>), dim3((unsigned)total), dim3(256), smem, st, a, pl);
     if (int rc = cm_launch_status("cm_scan_cl_bwd")) return rc;
     const int64_t n = (int64_t)a.ndir * a.batch * a.seqlen * RW + (int64_t)a.ndir * a.dim * NP;
     const int64_t blocks = (n + 255) / 256;
@@ -513,10 +630,13 @@ inline int bwd_dtr(const cm_scan_cl_bwd_args &a) { return a.dir[0].dt_rank > 16 
 
 }  // namespace
 
+extern "C" int cm_scan_cl_bwd_auto_chunks(int batch, int seqlen, int dim, int ndir) { return bwd_auto_chunks(batch, seqlen, dim, ndir, 0); }
+
 extern "C" int64_t cm_scan_cl_bwd_workspace_bytes(const cm_scan_cl_bwd_args *a) {
     if (!a || a->batch <= 0 || a->seqlen <= 0 || a->dim <= 0 || a->ndir <= 0) return 0;
     const int64_t P = bwd_dtr(*a), RW = P + 32, NP = 16 + P + 4, nx = (a->dim + 63) / 64;
-    return 4 * ((int64_t)a->ndir * nx * a->batch * a->seqlen * RW + (int64_t)a->ndir * a->batch * a->dim * NP);
+    const int64_t chunks = bwd_auto_chunks(a->batch, a->seqlen, a->dim, a->ndir, a->time_chunks);
+    return 4 * ((int64_t)a->ndir * nx * a->batch * a->seqlen * RW + (int64_t)a->ndir * a->batch * chunks * a->dim * (NP + 3 * 16));
 }
 
 extern "C" int cm_scan_cl_bwd(const cm_scan_cl_bwd_args *args) {

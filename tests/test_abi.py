@@ -61,6 +61,16 @@ def test_scan_chunk_policy_and_workspace_are_host_functions(native):
     a.seqlen, a.time_chunks = 50, 7                                             # 16-step chunks -> 4 chunks, not 7
     assert lib.cm_scan_cl_fwd_workspace_bytes(C.byref(a)) == 3 * 2 * 4 * 4 * 1024 * 16 * 4
     assert lib.cm_scan_cl_fwd_workspace_bytes(None) == 0
+    # the backward's policy: under 512 workgroups (two per CU) it cuts to about 1024, chunks of at least 128 steps
+    bauto = lib.cm_scan_cl_bwd_auto_chunks
+    assert bauto(32, 1000, 512, 2) == 1 and bauto(64, 1000, 512, 2) == 1
+    assert bauto(4, 4000, 1024, 2) == 8 and bauto(16, 1000, 512, 2) == 4 and bauto(1, 100, 64, 1) == 1
+    b = native.ScanClBwdArgs()
+    b.batch, b.seqlen, b.dim, b.ndir, b.time_chunks = 4, 4000, 1024, 2, 1
+    b.dir[0].dt_rank = b.dir[1].dt_rank = 32
+    one = lib.cm_scan_cl_bwd_workspace_bytes(C.byref(b))
+    b.time_chunks = 0
+    assert lib.cm_scan_cl_bwd_workspace_bytes(C.byref(b)) - one == 4 * 2 * 4 * 1024 * 7 * (16 + 32 + 4 + 3 * 16)
 
 
 def test_bad_arguments_are_rejected_not_fatal(native):

@@ -16,7 +16,7 @@ def close(a, b, rtol, atol):
     torch.testing.assert_close(a.detach().double().cpu(), b.detach().double().cpu(), rtol=rtol, atol=atol * scale)
 
 
-def _case(ops, b, l, e, rank, dtype, seed, lanes=0):
+def _case(ops, b, l, e, rank, dtype, seed, lanes=0, a_scale=1.0):
     P = 16 if rank <= 16 else 32
     RW = P + 32
     gen = torch.Generator().manual_seed(seed)
@@ -35,7 +35,7 @@ def _case(ops, b, l, e, rank, dtype, seed, lanes=0):
     for i, rev in enumerate((False, True)):
         u = ucat[:, :, e * i:e * (i + 1)]
         xd = xcat[:, :, RW * i:RW * (i + 1)].double()
-        A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3)
+        A = -torch.exp(torch.randn(e, 16, generator=gen) * 0.3) * a_scale
         Wdt = torch.randn(e, rank, generator=gen) * 0.3
         D, bias = torch.randn(e, generator=gen), torch.randn(e, generator=gen) - 1
         Wq = Wdt.to(dtype).double()                                                 # bf16 I/O: the product runs on the bf16-rounded weight
@@ -83,6 +83,37 @@ def test_scan_rows_bwd_two_directions(shape, dtype, rank):
     # deterministic: a second launch gives the same bits
     outs2 = ops.scan_cl_bwd(dirs, gz)
     for o, o2 in zip(outs, outs2):
+        for k in o:
+            assert torch.equal(o[k], o2[k]), k
+
+
+@pytest.mark.parametrize("shape,chunks", [((2, 37, 64), 2), ((1, 130, 200), 3), ((3, 64, 72), 4), ((2, 300, 512), 5), ((1, 1000, 128), 0)])
+@pytest.mark.parametrize("dtype,rank", [(torch.float32, 16), (torch.float32, 5), (torch.bfloat16, 16), (torch.bfloat16, 32)])
+def test_scan_rows_bwd_time_chunks(shape, chunks, dtype, rank):
+    """Launches cut along time (adjoint summaries per chunk, carry fold, full pass per chunk from the carried-in adjoint) against
+    the one-pass launch AND the oracle, with a slow decay (|A| x 0.03: the adjoint entering a chunk carries weight over hundreds
+    of steps).  chunks = 0: the library's own policy (1 x 1000 x 128 = 4 workgroups: it cuts)."""
+    from mamba_asr_amd import ops
+    b, l, e = shape
+    dirs, gz, refs, rank, P = _case(ops, b, l, e, rank, dtype, seed=l * 11 + e + rank, a_scale=0.03)
+    one = ops.scan_cl_bwd(dirs, gz, time_chunks=1)
+    one = [{k: v.clone() for k, v in o.items()} for o in one]
+    cut = ops.scan_cl_bwd(dirs, gz, time_chunks=chunks)
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    for o, c, r in zip(one, cut, refs):
+        for k in o:
+            # same arithmetic per step; only the adjoint's entry value is folded in a different order (P L + E per chunk)
+            close(c[k].float(), o[k].float().double(), 1e-4 if f32 else 1.6e-2, 1e-5 if f32 else 8e-3)
+        rt, at = (2e-3, 2e-4) if f32 else (2e-2, 1.2e-2)
+        close(c["du"].float(), r["du"].transpose(1, 2), rt, at)
+        close(c["dxdbl"][:, :, P:P + 16].float(), r["dB"].transpose(1, 2), rt, at)
+        close(c["dA"], r["dA"], 3e-3 if f32 else 2e-2, 3e-4 if f32 else 5e-3)
+    if chunks == 0:
+        from mamba_asr_amd import _native as N
+        assert N.lib().cm_scan_cl_bwd_auto_chunks(b, l, e, 2) > 1
+    cut2 = ops.scan_cl_bwd(dirs, gz, time_chunks=chunks)
+    for o, o2 in zip(cut, cut2):
         for k in o:
             assert torch.equal(o[k], o2[k]), k
 

@@ -3,7 +3,7 @@ us per launch, against the (B,E,T)-layout operator kernels (cm_selective_scan_bw
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
-from mamba_asr_amd import ops
+from mamba_asr_amd import ops, _native as N
 
 dev = "cuda"
 dt = torch.bfloat16
@@ -50,10 +50,12 @@ if __name__ == "__main__":
       for i in range(2):
           dirs[i].update(dout=dmix, du=ducat[:, :, e * i:e * (i + 1)], dz=dzcat[:, :, e * i:e * (i + 1)], dxdbl=dxcat[:, :, RW * i:RW * (i + 1)])
       t_bwd = timeit(lambda: ops.scan_cl_bwd(dirs, z), iters=10)
+      t_one = timeit(lambda: ops.scan_cl_bwd(dirs, z, time_chunks=1), iters=10)
+      nck = N.lib().cm_scan_cl_bwd_auto_chunks(b, l, e, 2)
       s = 2
       alg = 2 * b * l * (9 * e + 4 * 16) * s                     # SURVEY §8d's backward bytes per step and direction, both directions
       print(f"{b} x {l} x {e} (P {P}): forward {t_inf:7.1f} us, training forward (+ckpt, ypre) {t_trn:7.1f} us, backward (both directions, "
-            f"reduce included) {t_bwd:7.1f} us = {t_bwd / 2:6.1f} us per direction; {alg / t_bwd / 1e6:6.2f} TB/s = {alg / t_bwd / 1e6 / 8 * 100:4.1f} % of 8 TB/s")
+            f"reduce included, {nck} time chunk(s); uncut {t_one:7.1f} us) {t_bwd:7.1f} us = {t_bwd / 2:6.1f} us per direction; {alg / t_bwd / 1e6:6.2f} TB/s = {alg / t_bwd / 1e6 / 8 * 100:4.1f} % of 8 TB/s")
       if P == 16:
           # the operator-API kernels on (B, E, T)
           u = rnd(b, e, l).to(dt); delta = (rnd(b, e, l) * 0.5).to(dt); zz = rnd(b, e, l).to(dt)
