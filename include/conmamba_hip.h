@@ -398,14 +398,17 @@ typedef struct cm_ffn_elem_args {
     const float *bias;                        /* (dim) or NULL                                                                     */
     const float *res;                         /* forward, optional: (rows, dim) fp32 residual                                      */
     void        *y;                           /* forward out: I/O dtype, or fp32 with res                                          */
-    uint8_t     *mask;                        /* (rows, dim) bytes or NULL                                                         */
+    uint8_t     *mask;                        /* (rows, dim) bytes or NULL.  p > 0 drops with or without it: forward stores the
+                                                 decisions there when given; backward reads them, or re-derives them from seed     */
     const void  *dy;                          /* backward in                                                                       */
     void        *da;                          /* backward out, I/O dtype                                                           */
     float       *dbias;                       /* backward, optional: (dim) fp32, ACCUMULATED into                                  */
     float       *dbias_part;                  /* cm_bias_act_dropout_bwd_workspace_floats(rows, dim) floats, required with dbias   */
     float p, alpha;
-    uint64_t seed;
+    uint64_t seed;                            /* dropout stream (cm_dropout.h): element e of the (rows, dim) tensor                */
     void *stream;
+    void        *act_out;                     /* backward, optional (act 1, bf16): dropout(GELU(a + bias)) recomputed -- what the
+                                                 training forward of cm_ffn_fused fed to its second GEMM                            */
 } cm_ffn_elem_args;
 
 int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim);
@@ -786,6 +789,16 @@ typedef struct cm_ffn_args {
     const void  *proj_w;                /* (proj_dim, 256) bf16, cm_ffn_pack_weights' image                                */
     const float *proj_b;                /* (proj_dim) fp32 or NULL                                                          */
     void        *proj_out;              /* (rows, proj_dim) bf16                                                            */
+    /* optional, the TRAINING forward of the module (reference modules/Conmamba.py:597-617 with its two Dropouts live):
+         x_out = x + alpha * drop_p2( W2 drop_p1( GELU( bf16(W1 LN(x) + b1) ) ) + b2 )
+       with what the backward needs stored on the way: pre_out = bf16(W1 LN(x) + b1) and xn_out = bf16(LN(x)).  Dropout
+       decisions are cm_dropout.h's function of (seed, element index in the (rows, hidden) / (rows, 256) tensor): no mask is
+       stored, cm_bias_act_dropout_bwd re-derives it.  Requires x_out, no addend / n1 / n2 / projection / h_out. */
+    void        *pre_out;               /* (rows, hidden) bf16 or NULL                                                      */
+    void        *xn_out;                /* (rows, 256) bf16 or NULL                                                         */
+    float p1, p2;                       /* dropout probabilities behind the activation / behind the second Linear           */
+    uint64_t seed1, seed2;
+    float       *stats_out;             /* (2, rows) fp32 or NULL: mean, 1/std of LN(x)'s rows, as cm_layernorm_bwd reads them */
 } cm_ffn_args;
 
 int cm_ffn_fused(const cm_ffn_args *args);

@@ -89,7 +89,7 @@ class FfnElemArgs(C.Structure):
     _fields_ = [
         ("rows", i64), ("dim", i32), ("io_dtype", i32), ("act", i32), ("dy_f32", i32),
         ("a", vp), ("bias", fp), ("res", fp), ("y", vp), ("mask", vp), ("dy", vp), ("da", vp), ("dbias", fp), ("dbias_part", fp),
-        ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp),
+        ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp), ("act_out", vp),
     ]
 
 
@@ -248,6 +248,8 @@ class FfnArgs(C.Structure):
         ("n1_g", fp), ("n1_b", fp), ("n2_g", fp), ("n2_b", fp), ("x_out", fp), ("h_out", vp),
         ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
         ("proj_dim", i32), ("stream", vp), ("proj_w", vp), ("proj_b", fp), ("proj_out", vp),
+        ("pre_out", vp), ("xn_out", vp), ("p1", C.c_float), ("p2", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
+        ("stats_out", fp),
     ]
 
 

@@ -135,6 +135,24 @@ __device__ __forceinline__ uint32_t cm_gelu_bf16_pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2b));
 }
 
+// dropout(GELU(.)) of two bf16-valued pre-activations, rounded to a bf16 pair: the training forward (cm_ffn_fused) and the backward's
+// recomputation (cm_bias_act_dropout_bwd) both call THIS, so the weight-gradient GEMM sees the activations the forward used.
+__device__ __forceinline__ uint32_t cm_gelu_drop_bf16_pack2(float a, float b, uint32_t keep_a, uint32_t keep_b, float scale) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    const v2f x = {a, b};
+    v2f x2 = x * x;
+    x2 = v2f{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    v2f q = __builtin_elementwise_fma(x2, v2f{7.03033577e-04f * CM_LOG2E, 7.03033577e-04f * CM_LOG2E},
+                                      v2f{-7.40112920e-02f * CM_LOG2E, -7.40112920e-02f * CM_LOG2E});
+    q = __builtin_elementwise_fma(x2, q, v2f{-1.59501577f * CM_LOG2E, -1.59501577f * CM_LOG2E});
+    const v2f e = x * q;
+    const v2f d = v2f{cm_exp2(e.x), cm_exp2(e.y)} + v2f{1.0f, 1.0f};
+    const v2f m = {keep_a ? scale : 0.f, keep_b ? scale : 0.f};
+    const v2f r = (x * v2f{cm_rcp(d.x), cm_rcp(d.y)}) * m;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2b));
+}
+
 // softplus, beta=1, threshold=20 (torch default; reference selective_scan_interface.py:112).
 // For x < -15, log1p(e^x) == e^x to fp32 precision; using it avoids the 1+tiny cancellation.
 __device__ __forceinline__ float cm_softplus(float x) {

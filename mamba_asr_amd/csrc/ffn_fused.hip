@@ -16,6 +16,7 @@
 //     come from LDS, 4 ds_read_b128 per 16 MFMAs (64 B/clk/CU at full MFMA rate).
 //   * barriers wait on LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier), so the weight ring is not drained.
 #include "cm_common.h"
+#include "cm_dropout.h"
 #include <type_traits>
 
 
@@ -48,8 +49,12 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 // 3.4 / 10 us late, so that a CU's two workgroups are in different phases, was also tried: no effect.)
 // PROJ: the Linear that consumes h (the BiMamba in_proj after the layer's first feed-forward module, reference
 // bimamba.py:192-200) runs on the tile before it leaves the CU: proj_out = LN2(r) @ proj_w^T, h itself is not stored.
-template <bool ADD, int VAR = 0, bool PROJ = false>
+// TRAIN: the module's training forward (cm_ffn_args.pre_out ...): the slab goes to LDS as bf16(pre-activation), a row-wise pass stores
+// it (whole 512-byte row segments) and replaces it in place by dropout(GELU(.)) -- the activation is then a function of the STORED
+// value, which is what the backward differentiates and recomputes -- and the epilogue applies the second dropout.
+template <bool ADD, int VAR = 0, bool PROJ = false, bool TRAIN = false>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
+    constexpr int PFK = TRAIN ? 2 : PF;                          // the training variant carries its row-wise pass: a 2-deep ring keeps it at 256 VGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
     uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab
@@ -76,6 +81,8 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     // Buffer loads: one VGPR of lane offset, everything else in SGPRs / the immediate field.
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(W1), 0, F * D * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(W2), 0, F * D * 2, 0x00020000);
+    // training forward: the stored pre-activations, (rows, hidden) bf16 (element offsets fit 32 bits: rows x hidden < 2^31)
+    const __amdgpu_buffer_rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(p.pre_out, 0, TRAIN && p.pre_out ? (int)((int64_t)M * F * 2) : 0, 0x00020000);
     const int vl = lane * 16;
     const int kt2 = F / 32;                                       // tiles per 16-row band of W2
     auto wload = [&](int c, int s, bf16x8(&dst)[4], bool first = false) {
@@ -92,9 +99,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                                                          r2, vl, ((wave * 4 + mb) * kt2 + c * (CH / 32) + (s - 8)) * 1024, 0));
         }
     };
-    bf16x8 wq[PF][4];
+    bf16x8 wq[PFK][4];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) wload(0, s, wq[s], true);
+    for (int s = 0; s < PFK; ++s) wload(0, s, wq[s], true);
 
     for (int i = tid; i < p.hidden; i += NT) b1s[i] = p.b1[i];
 
@@ -134,6 +141,10 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                 q = fmaf(v[rd][i].x, v[rd][i].x, fmaf(v[rd][i].y, v[rd][i].y, fmaf(v[rd][i].z, v[rd][i].z, fmaf(v[rd][i].w, v[rd][i].w, q))));
             }
             const float rstd = rsqrtf(cm_group_sum<16>(q) * (1.f / D) + p.pre_eps);
+            if constexpr (TRAIN) {
+                const int trow = t0 + wv * 16 + rd * 4 + lq;
+                if (p.stats_out && l15 == 0 && trow < M) p.stats_out[trow] = mean, p.stats_out[(int64_t)M + trow] = rstd;
+            }
             uint16_t *dst = xn + (wv * 16 + rd * 4 + lq) * XS;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -148,6 +159,17 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
         }
     }
     lds_barrier();
+    if constexpr (TRAIN) {
+        if (p.xn_out) {                                           // the normalised tokens as the first GEMM reads them, whole rows
+            uint16_t *xo = reinterpret_cast<uint16_t *>(p.xn_out);
+#pragma unroll 2
+            for (int i = 0; i < TOK * 32 / NT; ++i) {
+                const int idx = tid + NT * i, row = idx >> 5, ch = idx & 31;
+                const uint4 v = *reinterpret_cast<const uint4 *>(xn + row * XS + ch * 8);
+                if (t0 + row < M) *reinterpret_cast<uint4 *>(xo + (int64_t)(t0 + row) * D + ch * 8) = v;
+            }
+        }
+    }
 
     // ---- main loop over hidden slabs
     f32x4 acc2[4][4];
@@ -186,12 +208,54 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc1[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc1[mb][nb], 0, 0, 0);
-            wload(c, s + PF, wq[s % PF]);
+                    acc1[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PFK][mb], cur[nb], acc1[mb][nb], 0, 0, 0);
+            wload(c, s + PFK, wq[s % PFK]);
             __builtin_amdgcn_sched_barrier(0);                    // keep the refill HERE: the scheduler otherwise sinks
         }                                                         // the loads to their use and the ring is gone
         // bias + GELU -> bf16 slab in LDS (token-major, hidden contiguous)
         if (c > 0) lds_barrier();                                 // every wave is done reading the previous slab
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 bv = *reinterpret_cast<const float4 *>(b1s + c * CH + wave * 64 + mb * 16 + lq * 4);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    uint2 pk;
+                    pk.x = pack2(acc1[mb][nb][0] + bv.x, acc1[mb][nb][1] + bv.y);
+                    pk.y = pack2(acc1[mb][nb][2] + bv.z, acc1[mb][nb][3] + bv.w);
+                    *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
+                }
+            }
+            lds_barrier();
+            // row-wise pass: 16-byte pieces, a wave instruction = two whole 512-byte row segments of the slab
+            constexpr int NPC = TOK * (CH / 8) / NT, NPH = 4;       // pieces per thread, pieces in flight
+            const bool drop = p.p1 > 0.f;
+            const uint32_t th1 = cm_drop_thresh(p.p1);
+            const float sc1 = drop ? cm_drop_scale(p.p1) : 1.f;
+            // piece i of this thread: row (tid >> 5) + 8 i, hidden columns 8 (tid & 31) ..: one 32-bit element offset, scalar steps
+            const uint32_t el0 = (uint32_t)(t0 + (tid >> 5)) * (uint32_t)F + (uint32_t)(c * CH + (tid & 31) * 8);
+            uint16_t *hrow = hc + (tid >> 5) * XS + (tid & 31) * 8;
+#pragma unroll
+            for (int i0 = 0; i0 < NPC; i0 += NPH) {
+                uint4 pv[NPH];
+#pragma unroll
+                for (int i = 0; i < NPH; ++i) pv[i] = *reinterpret_cast<const uint4 *>(hrow + (i0 + i) * 8 * XS);
+#pragma unroll
+                for (int i = 0; i < NPH; ++i) {
+                    const uint32_t el = el0 + (uint32_t)((i0 + i) * 8) * (uint32_t)F;
+                    if (p.pre_out)                                   // rows past the end fall outside the descriptor
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[i]), rpre, el * 2, 0, 0);
+                    const uint32_t keep = drop ? cm_drop_keep8(p.seed1, (uint64_t)(el >> 3), th1) : 0xffu;
+                    const uint32_t w[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = cm_gelu_drop_bf16_pack2(__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u),
+                                                                             (keep >> (2 * j)) & 1u, (keep >> (2 * j + 1)) & 1u, sc1);
+                    *reinterpret_cast<uint4 *>(hrow + (i0 + i) * 8 * XS) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 bv = *reinterpret_cast<const float4 *>(b1s + c * CH + wave * 64 + mb * 16 + lq * 4);
@@ -211,6 +275,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                 *reinterpret_cast<uint2 *>(hdst + nb * 16 * XS + mb * 16) = pk;
             }
         }
+        }
         lds_barrier();
         // GEMM 2: 64 output features x 64 tokens, K = this slab
         read_frags(hfrag, 0, bfa);
@@ -223,9 +288,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc2[mb][nb], 0, 0, 0);
-            if (s + PF < 16) wload(c, s + PF, wq[s % PF]);
-            else if constexpr (!LAST) wload(c + 1, s + PF - 16, wq[s % PF]);   // next slab's first steps
+                    acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PFK][mb], cur[nb], acc2[mb][nb], 0, 0, 0);
+            if (s + PFK < 16) wload(c, s + PFK, wq[s % PFK]);
+            else if constexpr (!LAST) wload(c + 1, s + PFK - 16, wq[s % PFK]);   // next slab's first steps
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -279,6 +344,18 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
         const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + f0 + mb * 16);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
+            if constexpr (TRAIN) {
+                if (p.p2 > 0.f) {                                     // second dropout: on W2 g + b2, in front of the scaled residual add
+                    const int64_t e0 = (int64_t)(t0 + th * 64 + nb * 16 + l15) * D + f0 + mb * 16;
+                    const uint32_t keep = cm_drop_keep4(p.seed2, (uint64_t)e0 >> 3, (int)((e0 >> 2) & 1), cm_drop_thresh(p.p2));
+                    const float sc2 = cm_drop_scale(p.p2);
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r[nb][mb][j] = fmaf(p.alpha, ((keep >> j) & 1u) ? (acc2[mb][nb][j] + bb[j]) * sc2 : 0.f, r[nb][mb][j]);
+                    continue;
+                }
+            }
             r[nb][mb][0] = fmaf(p.alpha, acc2[mb][nb][0] + bv.x, r[nb][mb][0]);
             r[nb][mb][1] = fmaf(p.alpha, acc2[mb][nb][1] + bv.y, r[nb][mb][1]);
             r[nb][mb][2] = fmaf(p.alpha, acc2[mb][nb][2] + bv.z, r[nb][mb][2]);
@@ -383,7 +460,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                                                          rp, vl, (((ps * 256 + wave * 64) / 16 + mb) * (D / 32) + s) * 1024, 0));
         };
 #pragma unroll
-        for (int s = 0; s < PF; ++s) pload(0, s, wq[s]);          // in flight under the LayerNorm below
+        for (int s = 0; s < PFK; ++s) pload(0, s, wq[s]);          // in flight under the LayerNorm below
         if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
         lds_barrier();                                            // (layer_norm's own barriers already order the last GEMM's reads)
 #pragma unroll
@@ -415,9 +492,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                 for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PF][mb], cur[nb], acc[mb][nb], 0, 0, 0);
-                if (s + PF < 8) pload(ps, s + PF, wq[s % PF]);
-                else if (ps + 1 < nps) pload(ps + 1, s + PF - 8, wq[s % PF]);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s % PFK][mb], cur[nb], acc[mb][nb], 0, 0, 0);
+                if (s + PFK < 8) pload(ps, s + PFK, wq[s % PFK]);
+                else if (ps + 1 < nps) pload(ps + 1, s + PFK - 8, wq[s % PFK]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // bias, bf16, and out through LDS: a lane's accumulators are 4 features of 16 different tokens (8-byte pieces of
@@ -482,12 +559,12 @@ __global__ void ffn_pack_kernel(const uint16_t *__restrict__ w, uint16_t *__rest
     *reinterpret_cast<uint4 *>(out + piece * 8) = *reinterpret_cast<const uint4 *>(w + (int64_t)r * K + k);
 }
 
-template <bool ADD, int VAR, bool PROJ = false>
+template <bool ADD, int VAR, bool PROJ = false, bool TRAIN = false>
 int launch_var(const cm_ffn_args &a) {
     const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)4 * TOK * sizeof(float) + (size_t)a.hidden * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<ADD, VAR, PROJ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<ADD, VAR, PROJ, TRAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -496,7 +573,7 @@ int launch_var(const cm_ffn_args &a) {
         attr_done = true;
     }
     dim3 grid((a.rows + TOK - 1) / TOK);
-    hipLaunchKernelGGL((ffn_fused_kernel<ADD, VAR, PROJ>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    hipLaunchKernelGGL((ffn_fused_kernel<ADD, VAR, PROJ, TRAIN>), grid, dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_ffn_fused");
 }
 
@@ -551,5 +628,15 @@ extern "C" int cm_ffn_fused(const cm_ffn_args *args) {
                    (!a.n1_g || (cm_aligned(a.n1_g, 16) && cm_aligned(a.n1_b, 16))) &&
                    (!a.n2_g || (cm_aligned(a.n2_g, 16) && cm_aligned(a.n2_b, 16))),
                CM_EALIGN, "ffn_fused: tensors must be 16-byte aligned");
+    const bool train = a.pre_out || a.xn_out || a.stats_out || a.p1 > 0.f || a.p2 > 0.f;
+    if (train) {
+        CM_REQUIRE(a.x_out && !a.addend && !a.n1_g && !a.n2_g && !a.proj_w && !a.h_out, CM_EINVAL,
+                   "ffn_fused: the training forward writes x_out (+ pre_out, xn_out) only: no addend, n1, n2, projection or h_out");
+        CM_REQUIRE(a.p1 >= 0.f && a.p1 < 1.f && a.p2 >= 0.f && a.p2 < 1.f, CM_EINVAL, "ffn_fused: dropout probabilities must be in [0, 1)");
+        CM_REQUIRE((!a.pre_out || cm_aligned(a.pre_out, 16)) && (!a.xn_out || cm_aligned(a.xn_out, 16)), CM_EALIGN,
+                   "ffn_fused: pre_out / xn_out must be 16-byte aligned");
+        CM_REQUIRE((int64_t)a.rows * a.hidden * 2 < ((int64_t)1 << 32), CM_EUNSUPPORTED, "ffn_fused: rows x hidden too large for the training forward's 32-bit offsets");
+        return launch_var<false, 0, false, true>(a);
+    }
     return a.addend ? launch<true>(a) : launch<false>(a);
 }

@@ -5,19 +5,32 @@
 //                             or, with `res`:  y = res + alpha * dropout(a + bias)   (fp32 residual stream)
 //   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias);  dbias = column sums of da, through per-workgroup
 //                             partial rows + a fixed-order second pass (deterministic)
-// Dropout masks are one byte per element, drawn from a counter hash of (seed, element index): any Bernoulli(1 - p) mask is the
-// reference's semantics (torch.nn.Dropout); the host draws the seed from torch's seeded generator.
+// Dropout decisions are cm_dropout.h's function of (seed, element index): any Bernoulli(1 - p) mask is the reference's semantics
+// (torch.nn.Dropout); the host draws the seed from torch's seeded generator.  The forward stores the mask (one byte per element)
+// only when asked to; the backward reads a stored mask or, without one, re-derives the decisions from the seed (the training
+// forward of cm_ffn_fused stores none).
 #include "cm_common.h"
+#include "cm_dropout.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {            // murmur3 finaliser
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    const uint32_t h = hash32((uint32_t)idx * 0x9E3779B9u + (uint32_t)seed) ^ hash32((uint32_t)(idx >> 32) + (uint32_t)(seed >> 32) + 0x7F4A7C15u);
-    return hash32(h) >= thresh;                                      // P(keep) = 1 - thresh / 2^32
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// d/dx of the bf16 GELU form x sigmoid(x P(x^2)) (cm_gelu_bf16): s + x s (1 - s) (P + 2 x^2 P'), on two values; for results
+// that are rounded to bf16 (|error| against the erf form's derivative < 2e-4)
+__device__ __forceinline__ v2f gelu_grad_bf16_2(v2f x) {
+    constexpr float c2 = 7.03033577e-04f * CM_LOG2E, c1 = -7.40112920e-02f * CM_LOG2E, c0 = -1.59501577f * CM_LOG2E;
+    v2f x2 = x * x;
+    x2 = v2f{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    const v2f t = __builtin_elementwise_fma(x2, v2f{c2, c2}, v2f{c1, c1});
+    const v2f q = __builtin_elementwise_fma(x2, t, v2f{c0, c0});                        // e = x q, s = 1 / (1 + 2^e)
+    const v2f t2 = __builtin_elementwise_fma(x2, v2f{2.f * c2, 2.f * c2}, v2f{c1, c1});
+    const v2f de = __builtin_elementwise_fma(x2 + x2, t2, q);                           // de/dx
+    const v2f e = x * q;
+    const v2f d = v2f{cm_exp2(e.x), cm_exp2(e.y)} + v2f{1.0f, 1.0f};
+    const v2f s = {cm_rcp(d.x), cm_rcp(d.y)};
+    const v2f ss = __builtin_elementwise_fma(-s, s, s);                                 // s (1 - s)
+    return __builtin_elementwise_fma(x * ss, de * v2f{-CM_LN2, -CM_LN2}, s);
 }
 // d/dx of 0.5 x erfc(-x / sqrt 2)
 __device__ __forceinline__ float gelu_grad(float x) {
@@ -55,22 +68,19 @@ __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const cm_ffn_
     const int c = (int)(v % vpr) * 8;
     float a[8], y[8];
     ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
-    const bool drop = p.mask != nullptr;
-    const float scale = drop ? 1.f / (1.f - p.p) : 1.f;
-    const uint32_t thresh = drop ? (uint32_t)fminf(p.p * 4294967296.f, 4294967295.f) : 0u;
+    const bool drop = p.p > 0.f;
+    const float scale = drop ? cm_drop_scale(p.p) : 1.f;
+    const uint32_t keep8 = drop ? cm_drop_keep8(p.seed, (uint64_t)v, cm_drop_thresh(p.p)) : 0xffu;
     uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float t = a[k] + (p.bias ? p.bias[c + k] : 0.f);
-        if (p.act == 1) t = cm_gelu(t);
-        bool keep = true;
-        if (drop) {
-            keep = keep_elem(p.seed, e0 + k, thresh);
-            (k < 4 ? mlo : mhi) |= (keep ? 1u : 0u) << (8 * (k & 3));
-        }
+        if (p.act == 1) t = sizeof(YT) == 2 ? cm_gelu_bf16(t) : cm_gelu(t);
+        const bool keep = (keep8 >> k) & 1u;
+        (k < 4 ? mlo : mhi) |= (keep ? 1u : 0u) << (8 * (k & 3));
         y[k] = keep ? t * scale : 0.f;
     }
-    if (drop) *reinterpret_cast<uint2 *>(p.mask + e0) = make_uint2(mlo, mhi);
+    if (drop && p.mask) *reinterpret_cast<uint2 *>(p.mask + e0) = make_uint2(mlo, mhi);
     if (p.res) {                                                     // y = res + alpha * dropout(a + bias), fp32 stream
         float r[8];
         ld_vec<float>(p.res + e0, r);
@@ -89,8 +99,9 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
     const int tr = threadIdx.x / vpr, tc = threadIdx.x % vpr;
     const bool live = tr < rp;
     const int c = tc * 8;
-    const bool drop = p.mask != nullptr;
-    const float scale = p.alpha * (drop ? 1.f / (1.f - p.p) : 1.f);
+    const bool drop = p.p > 0.f;
+    const float dscale = drop ? cm_drop_scale(p.p) : 1.f, scale = p.alpha * dscale;
+    const uint32_t thresh = cm_drop_thresh(p.p);
     float bs[8], acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs[k] = p.bias ? p.bias[live ? c + k : 0] : 0.f, acc[k] = 0.f;
@@ -100,16 +111,46 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
             const int64_t e0 = r * p.dim + c;
             float dy[8], da[8];
             ld_vec<DYT>(reinterpret_cast<const DYT *>(p.dy) + e0, dy);
-            uint2 m = make_uint2(0x01010101u, 0x01010101u);
-            if (drop) m = *reinterpret_cast<const uint2 *>(p.mask + e0);
-            float a[8];
-            if (p.act == 1) ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
+            uint32_t keep8 = 0xffu;
+            if (drop) {
+                if (p.mask) {
+                    const uint2 m = *reinterpret_cast<const uint2 *>(p.mask + e0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool keep = ((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 1u;
-                float g = keep ? dy[k] * scale : 0.f;
-                if (p.act == 1) g *= gelu_grad(a[k] + bs[k]);
-                da[k] = g;
+                    for (int k = 0; k < 8; ++k) keep8 = (keep8 & ~(1u << k)) | ((((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 1u) << k);
+                } else keep8 = cm_drop_keep8(p.seed, (uint64_t)e0 >> 3, thresh);
+            }
+            float a[8];
+            if (p.act == 1) {
+                ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += bs[k];
+            }
+            if constexpr (sizeof(AT) == 2) {
+                if (p.act == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const v2f gg = gelu_grad_bf16_2(v2f{a[k], a[k + 1]});
+                        da[k] = ((keep8 >> k) & 1u) ? dy[k] * scale * gg.x : 0.f;
+                        da[k + 1] = ((keep8 >> (k + 1)) & 1u) ? dy[k + 1] * scale * gg.y : 0.f;
+                    }
+                    if (p.act_out) {                                 // the activation the forward fed to the next GEMM, recomputed
+                        uint32_t o[4];
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2)
+                            o[k / 2] = cm_gelu_drop_bf16_pack2(a[k], a[k + 1], (keep8 >> k) & 1u, (keep8 >> (k + 1)) & 1u, dscale);
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<cm_bf16 *>(p.act_out) + e0) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) da[k] = ((keep8 >> k) & 1u) ? dy[k] * scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float g = ((keep8 >> k) & 1u) ? dy[k] * scale : 0.f;
+                    if (p.act == 1) g *= gelu_grad(a[k]);
+                    da[k] = g;
+                }
             }
             st_vec<AT>(reinterpret_cast<AT *>(p.da) + e0, da);
             if (p.dbias_part) {
@@ -248,7 +289,10 @@ int check(const cm_ffn_elem_args &a, const char *what) {
     CM_REQUIRE(a.io_dtype == CM_BF16 || a.io_dtype == CM_F32, CM_EUNSUPPORTED, "%s: io dtype %d unsupported", what, a.io_dtype);
     CM_REQUIRE(a.act >= 0 && a.act <= 2, CM_EUNSUPPORTED, "%s: act %d (0 none, 1 GELU, 2 GLU)", what, a.act);
     CM_REQUIRE(a.act != 2 || (!a.mask && !a.res && a.dim <= 1024), CM_EUNSUPPORTED, "%s: GLU takes no dropout / residual, dim <= 1024", what);
-    CM_REQUIRE(!a.mask || (a.p > 0.f && a.p < 1.f && cm_aligned(a.mask, 8)), CM_EINVAL, "%s: mask needs 0 < p < 1 and 8-byte alignment", what);
+    CM_REQUIRE(a.p >= 0.f && a.p < 1.f && (!a.mask || (a.p > 0.f && cm_aligned(a.mask, 8))), CM_EINVAL,
+               "%s: dropout needs 0 <= p < 1; a mask needs p > 0 and 8-byte alignment", what);
+    CM_REQUIRE(!a.act_out || (a.act == 1 && a.io_dtype == CM_BF16 && cm_aligned(a.act_out, 16)), CM_EUNSUPPORTED,
+               "%s: act_out (the recomputed activation) is the bf16 GELU form's, 16-byte aligned", what);
     return CM_OK;
 }
 

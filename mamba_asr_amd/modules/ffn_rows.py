@@ -8,7 +8,12 @@ leaves it to torch autograd: 8 element-wise launches forward and about 10 backwa
 LayerNorm forward / backward (csrc/layernorm_train.hip), bias + GELU + dropout and bias + dropout + scaled residual add as one
 kernel each (csrc/ffn_train.hip), their gradients with the bias-gradient column sums inside (deterministic), weight gradients
 as per-utterance batched GEMMs folded by cm_sum_leading.  The GEMMs themselves stay library calls (MFMA only for the
-projections, BASELINE.json north_star)."""
+projections, BASELINE.json north_star).
+
+bf16, d_model 256 (ConMamba-large): the FORWARD is cm_ffn_fused's training variant -- one kernel, the hidden activations stay in
+LDS; it stores the pre-activation (bf16), the normalised input and the LayerNorm statistics for the backward and no dropout
+mask (csrc/cm_dropout.h: the decisions are a function of (seed, element index), re-derived in the backward, which also
+recomputes the activation the second GEMM saw for its weight gradient).  CM_FFN_FUSED_TRAIN=0 keeps the kernel-per-stage forward."""
 from __future__ import annotations
 
 import os
@@ -21,6 +26,11 @@ from .. import ops
 
 # CM_FFN_ROWS=0: the module tree runs as written (torch element-wise kernels between the GEMMs)
 ENABLED = os.environ.get("CM_FFN_ROWS", "1") == "1"
+FUSED_TRAIN = os.environ.get("CM_FFN_FUSED_TRAIN", "1") == "1"
+
+
+def _fused_ok(cdt, D, F_, rows):
+    return FUSED_TRAIN and cdt == torch.bfloat16 and ops.ffn_supported(D, F_, cdt) and F_ <= 2048 and rows * F_ * 2 < 2 ** 32
 
 
 def supported(x, ln, lin1, act, lin2) -> bool:
@@ -41,6 +51,18 @@ class FfnRowsFn(torch.autograd.Function):
         B, T, D = x.shape
         x2 = x.detach().reshape(B * T, D)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        if _fused_ok(cdt, D, w1.shape[0], B * T):
+            s1 = ops.draw_seed() if p1 > 0.0 else 0
+            s2 = ops.draw_seed() if p2 > 0.0 else 0
+            out = torch.empty_like(x2)
+            f32 = lambda t: t.detach().float().contiguous()
+            _, (pre, h, stats) = ops.ffn_fused(x2, (f32(lnw), f32(lnb), eps), ops.pack_cached(w1), f32(b1), ops.pack_cached(w2), f32(b2),
+                                               alpha=alpha, x_out=out, train=(p1, p2, s1, s2))
+            ctx.save_for_backward(x2, stats, h, pre, lnw, w1, w2)
+            ctx.cfg = (eps, p1, p2, alpha, cdt, (B, T, D))
+            ctx.seeds = (s1, s2)
+            return out.view(B, T, D)
+        ctx.seeds = None
         h, x2s, stats = ops.layernorm_fwd(x2, lnw, lnb, eps, cdt)
         w1c, w2c = ops.cast_cached(w1, cdt), ops.cast_cached(w2, cdt)
         a1 = torch.mm(h, w1c.t())
@@ -54,6 +76,8 @@ class FfnRowsFn(torch.autograd.Function):
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
+        if ctx.seeds is not None:
+            return FfnRowsFn._backward_fused(ctx, dout)
         x2s, stats, h, a1, g, m1, m2, lnw, w1, b1, w2 = ctx.saved_tensors
         eps, p1, p2, alpha, cdt, (B, T, D) = ctx.cfg
         F_ = a1.shape[1]
@@ -71,6 +95,30 @@ class FfnRowsFn(torch.autograd.Function):
         dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2s, stats, lnw, eps, dres=dout2)       # dx = dout + LayerNorm'(dh) in one pass
         dx = dx.view(B, T, D)
         return dx, dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None
+
+
+def _backward_fused(ctx, dout):
+    x2, stats, h, pre, lnw, w1, w2 = ctx.saved_tensors
+    eps, p1, p2, alpha, cdt, (B, T, D) = ctx.cfg
+    s1, s2 = ctx.seeds
+    F_ = pre.shape[1]
+    dout2 = dout.reshape(B * T, D)
+    dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
+    if dout2.dtype != torch.float32:
+        dout2 = dout2.float()
+    w1c, w2c = ops.cast_cached(w1, cdt), ops.cast_cached(w2, cdt)
+    da2, db2 = ops.bias_act_dropout_bwd(dout2, None, p2, act=0, alpha=alpha, out_dtype=cdt, seed=s2 if p2 > 0.0 else None)
+    dg = torch.mm(da2, w2c)
+    # pre already holds the bias; one pass gives the first GEMM's output gradient AND the activation the forward's second GEMM saw
+    da1, db1, g = ops.bias_act_dropout_bwd(dg, None, p1, a=pre, act=1, seed=s1 if p1 > 0.0 else None, want_act=True)
+    dw2 = ops.sum_leading(torch.bmm(da2.view(B, T, D).transpose(1, 2), g.view(B, T, F_)))
+    dh = torch.mm(da1, w1c)
+    dw1 = ops.sum_leading(torch.bmm(da1.view(B, T, F_).transpose(1, 2), h.view(B, T, D)))
+    dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2, stats, lnw, eps, dres=dout2)
+    return dx.view(B, T, D), dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None
+
+
+FfnRowsFn._backward_fused = staticmethod(_backward_fused)
 
 
 def ffn_rows(x, ln, lin1, drop1, lin2, drop2, alpha):

@@ -61,6 +61,20 @@ def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+def pack_cached(p: torch.Tensor) -> "PackedWeight":
+    """p (2-D parameter) as a bf16 PackedWeight (cm_ffn_fused's fragment-tiled image), cached like cast_cached."""
+    c = getattr(p, "_cm_pack", None)
+    key = (p._version, p.data_ptr())
+    if c is not None and c[0] == key and c[1].data.device == p.device:
+        return c[1]
+    pw = PackedWeight(cast_cached(p, torch.bfloat16))
+    try:
+        p._cm_pack = (key, pw)
+    except (AttributeError, RuntimeError):
+        pass
+    return pw
+
+
 def invalidate_caches(module: torch.nn.Module) -> None:
     """Drop every cached low-precision weight copy under ``module`` (cast_cached's per-parameter copies and the fused
     path's per-layer images).  The caches key on (parameter version, storage pointer): in-place writes made under
@@ -68,6 +82,8 @@ def invalidate_caches(module: torch.nn.Module) -> None:
     THROUGH ``p.data`` (``p.data.copy_()``, EMA / SWA code, vector_to_parameters) are not -- call this after them.
     load_state_dict calls it by itself (hook installed by asr.ConMambaASR)."""
     for p in module.parameters():
+        if hasattr(p, "_cm_pack"):
+            del p._cm_pack
         if hasattr(p, "_cm_cast"):
             try:
                 del p._cm_cast
@@ -453,29 +469,33 @@ def draw_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
-def bias_act_dropout_fwd(a, bias, act=0, p=0.0, res=None, alpha=1.0):
+def bias_act_dropout_fwd(a, bias, act=0, p=0.0, res=None, alpha=1.0, seed=None, store_mask=True):
     """y = dropout(act(a + bias)) in a's dtype, or with ``res`` (fp32, a's shape) y = res + alpha * dropout(a + bias) in fp32
-    (cm_bias_act_dropout_fwd).  a (rows, dim) contiguous bf16 / fp32; act 0 none, 1 GELU.  -> (y, mask or None)."""
+    (cm_bias_act_dropout_fwd).  a (rows, dim) contiguous bf16 / fp32; act 0 none, 1 GELU.  -> (y, mask or None).
+    The keep decisions are a function of (seed, element index) (csrc/cm_dropout.h): with ``seed`` given (draw_seed()) and
+    ``store_mask=False`` no mask is written and bias_act_dropout_bwd re-derives it from the same seed."""
     _dev_check(a, bias, res)
     if a.dim() != 2 or not a.is_contiguous() or a.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("bias_act_dropout_fwd: a must be a contiguous (rows, dim) bf16 / fp32 tensor")
     rows, dim = a.shape
     args = _elem_args(rows, dim, a.dtype, act, p, alpha)
     bs = _f32c(bias)
-    mask = torch.empty((rows, dim), dtype=torch.uint8, device=a.device) if p > 0.0 else None
+    mask = torch.empty((rows, dim), dtype=torch.uint8, device=a.device) if (p > 0.0 and store_mask) else None
     if res is not None and (res.dtype != torch.float32 or not res.is_contiguous() or res.shape != a.shape):
         raise RuntimeError("bias_act_dropout_fwd: res must be a contiguous fp32 tensor of a's shape")
     y = torch.empty((rows, dim), dtype=torch.float32 if res is not None else a.dtype, device=a.device)
     args.a, args.bias, args.res, args.y, args.mask = _ptr(a), _ptr(bs), _ptr(res), _ptr(y), _ptr(mask)
-    if mask is not None:
-        args.seed = draw_seed()
+    if p > 0.0:
+        args.seed = draw_seed() if seed is None else int(seed)
     _launch("cm_bias_act_dropout_fwd", N.lib().cm_bias_act_dropout_fwd, args, units=rows)
     return y, mask
 
 
-def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_dtype=None, want_dbias=True):
+def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_dtype=None, want_dbias=True, seed=None, want_act=False):
     """da = alpha * dy * mask / (1 - p) * act'(a + bias) in ``out_dtype`` (default a's / dy's dtype); dbias = column sums of da
-    (fp32, deterministic) (cm_bias_act_dropout_bwd).  dy (rows, dim) fp32 or the I/O dtype.  -> (da, dbias or None)."""
+    (fp32, deterministic) (cm_bias_act_dropout_bwd).  dy (rows, dim) fp32 or the I/O dtype.  -> (da, dbias or None).
+    ``mask`` None with ``seed`` given: the decisions are re-derived from the seed.  ``want_act`` (act 1, bf16): also returns
+    dropout(GELU(a + bias)) recomputed, as cm_ffn_fused's training forward fed it to its second GEMM -> (da, dbias, act)."""
     _dev_check(dy, mask, a, bias)
     if dy.dim() != 2 or not dy.is_contiguous():
         raise RuntimeError("bias_act_dropout_bwd: dy must be a contiguous (rows, dim) tensor")
@@ -485,9 +505,15 @@ def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_d
         raise RuntimeError("bias_act_dropout_bwd: dtypes must be fp32 / bf16, dy fp32 or the I/O dtype")
     if a is not None and (a.dtype != io or not a.is_contiguous() or a.shape != dy.shape):
         raise RuntimeError("bias_act_dropout_bwd: a must be contiguous, of dy's shape, in the I/O dtype")
-    args = _elem_args(rows, dim, io, act, p if mask is not None else 0.0, alpha)
+    args = _elem_args(rows, dim, io, act, p if (mask is not None or seed is not None) else 0.0, alpha)
+    if seed is not None:
+        args.seed = int(seed)
     bs = _f32c(bias)
     da = torch.empty((rows, dim), dtype=io, device=dy.device)
+    act_out = None
+    if want_act:
+        act_out = torch.empty((rows, dim), dtype=io, device=dy.device)
+        args.act_out = _ptr(act_out)
     args.a, args.bias, args.mask, args.dy, args.da = _ptr(a), _ptr(bs), _ptr(mask), _ptr(dy), _ptr(da)
     args.dy_f32 = int(dy.dtype == torch.float32 and io != torch.float32)
     dbias = None
@@ -498,7 +524,7 @@ def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_d
         dbias.zero_()
         args.dbias, args.dbias_part = _ptr(dbias), _ptr(ws)
     _launch("cm_bias_act_dropout_bwd", N.lib().cm_bias_act_dropout_bwd, args, units=rows)
-    return da, dbias
+    return (da, dbias, act_out) if want_act else (da, dbias)
 
 
 def bias_glu_fwd(a, bias):
@@ -1203,14 +1229,17 @@ class PackedWeight:
 
 
 def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0, norm1=None, norm2=None,
-              x_out=None, want_h=True, h_dtype=torch.bfloat16, proj_w=None, proj_b=None, proj_out=None):
+              x_out=None, want_h=True, h_dtype=torch.bfloat16, proj_w=None, proj_b=None, proj_out=None, train=None):
     """Whole feed-forward module on the fp32 residual stream (cm_ffn_fused):
         xin = x + add_scale*addend;  r = xin + alpha*(W2 gelu(W1 LN_pre(xin) + b1) + b2);  r = LN1(r) if norm1;
         x_out <- r (x itself when x_out is None);  returns h = LN2(r) (or r when norm2 is None) in h_dtype if want_h.
     x (rows, 256) fp32; w1 (hidden, 256) / w2 (256, hidden) bf16 tensors or PackedWeight (pack once, reuse); b1/b2 and
     LayerNorm parameters fp32; addend (rows, 256) bf16; norm = (weight, bias, eps).
     With ``proj_w`` (PackedWeight (P, 256), P % 256 == 0; ``proj_b`` fp32 (P) or None) the Linear that consumes h runs in the
-    same kernel and (rows, P) bf16 = h @ proj_w^T (+ proj_b) is returned in h's place; h itself is not stored."""
+    same kernel and (rows, P) bf16 = h @ proj_w^T (+ proj_b) is returned in h's place; h itself is not stored.
+    ``train`` = (p1, p2, seed1, seed2): the module's TRAINING forward, x_out = x + alpha * drop_p2(W2 drop_p1(gelu(bf16(W1 LN(x) + b1))) + b2)
+    with the backward's inputs stored on the way -> (x_out, (pre, xn, stats)): pre (rows, hidden) bf16 = W1 LN(x) + b1, xn (rows, 256)
+    bf16 = LN(x), stats (2, rows) fp32 = the rows' mean and 1/std (layernorm_bwd's input); the dropout decisions are cm_dropout.h's function of (seed, element index) (no mask is stored)."""
     _dev_check(x, b1, b2, addend, proj_b)
     rows, d = x.shape
     if x.dtype != torch.float32 or not x.is_contiguous():
@@ -1239,6 +1268,17 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
     xo = x if x_out is None else x_out
     a.x_out = _ptr(xo)
     h = None
+    if train is not None:
+        if addend is not None or norm1 is not None or norm2 is not None or proj_w is not None:
+            raise RuntimeError("ffn_fused: the training forward takes no addend / norm1 / norm2 / projection")
+        pre = torch.empty((rows, w1.shape[0]), dtype=torch.bfloat16, device=x.device)
+        xn = torch.empty((rows, d), dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        a.pre_out, a.xn_out, a.stats_out = _ptr(pre), _ptr(xn), _ptr(stats)
+        a.p1, a.p2, a.seed1, a.seed2 = float(train[0]), float(train[1]), int(train[2]), int(train[3])
+        a.stream = _stream()
+        _launch("cm_ffn_fused", N.lib().cm_ffn_fused, a, units=rows)
+        return xo, (pre, xn, stats)
     if proj_w is not None:
         if not isinstance(proj_w, PackedWeight) or proj_w.shape[1] != d or proj_w.shape[0] % 256 or proj_w.shape[0] > 4096:
             raise RuntimeError("ffn_fused: proj_w must be a PackedWeight of shape (P, 256), P a multiple of 256 up to 4096")

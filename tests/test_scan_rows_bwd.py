@@ -235,6 +235,106 @@ def test_ffn_rows_node_vs_module_tree(dtype, monkeypatch):
     assert torch.allclose(keep, keep.round(), atol=1e-3)
 
 
+def _drop_masks(ops, rows, dim, p, seed):
+    """The keep decisions of csrc/cm_dropout.h for a (rows, dim) tensor, through the element-wise kernel's stored mask."""
+    z = torch.zeros(rows, dim, device=DEV, dtype=torch.bfloat16)
+    _, m = ops.bias_act_dropout_fwd(z, None, act=0, p=p, seed=seed, store_mask=True)
+    return m.bool()
+
+
+@pytest.mark.parametrize("rows,hidden", [(300, 1024), (64, 256), (1000, 2048)])
+@pytest.mark.parametrize("p1,p2", [(0.0, 0.0), (0.1, 0.1), (0.3, 0.0)])
+def test_ffn_fused_training_forward(rows, hidden, p1, p2):
+    """cm_ffn_fused's training variant: x_out, the stored pre-activation / normalised input / LayerNorm statistics, and both
+    dropouts (decisions = cm_dropout.h's function of (seed, index), read back through the element-wise kernel's mask) against
+    the same arithmetic in torch: LN in fp32 -> bf16, GEMM 1 in fp32 on bf16 inputs + bias -> bf16, GELU (erf) x mask x scale ->
+    bf16, GEMM 2 + bias, mask x scale, x + alpha x that."""
+    from mamba_asr_amd import ops
+    g = torch.Generator().manual_seed(rows + hidden)
+    D = 256
+    x = torch.randn(rows, D, generator=g).to(DEV)
+    lnw, lnb = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    w1 = (torch.randn(hidden, D, generator=g) / 16).to(DEV).bfloat16()
+    w2 = (torch.randn(D, hidden, generator=g) / (hidden ** 0.5)).to(DEV).bfloat16()
+    b1, b2 = (0.1 * torch.randn(hidden, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    s1, s2 = 1234567 + rows, 7654321 + hidden
+    out = torch.empty_like(x)
+    _, (pre, xn, stats) = ops.ffn_fused(x, (lnw, lnb, 1e-5), w1, b1, w2, b2, alpha=0.5, x_out=out, train=(p1, p2, s1, s2))
+    torch.cuda.synchronize()
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    close(stats[0], mean, 1e-5, 1e-5)
+    close(stats[1], (var + 1e-5).rsqrt(), 1e-4, 1e-5)
+    xn_ref = torch.nn.functional.layer_norm(x, (D,), lnw, lnb, 1e-5)
+    close(xn.float(), xn_ref, 1e-2, 1e-2)
+    pre_ref = xn.float() @ w1.float().t() + b1                                # from the kernel's own bf16 xn: isolates GEMM 1
+    close(pre.float(), pre_ref, 1e-2, 1e-2)
+    sc = lambda p: 1.0 / (1.0 - round(p * 65536) / 65536.0)
+    m1 = _drop_masks(ops, rows, hidden, p1, s1) if p1 > 0 else torch.ones(rows, hidden, dtype=torch.bool, device=DEV)
+    m2 = _drop_masks(ops, rows, D, p2, s2) if p2 > 0 else torch.ones(rows, D, dtype=torch.bool, device=DEV)
+    if p1 > 0:
+        assert abs(float(m1.float().mean()) - (1 - p1)) < 0.01
+    act = (torch.nn.functional.gelu(pre.float()) * m1 * sc(p1)).bfloat16()
+    y2 = (act.float() @ w2.float().t() + b2) * m2 * sc(p2)
+    close(out, x + 0.5 * y2, 1e-2, 1e-2)
+    if p2 > 0:
+        # a dropped element of the second dropout leaves the residual stream untouched: the decisions are the mask's, exactly
+        assert torch.equal((out == x), ~m2 | (y2 == 0))
+    # what the backward recomputes as "the activation the second GEMM saw" is the forward's: same bits through the same function
+    da, db, act_k = ops.bias_act_dropout_bwd(torch.ones(rows, hidden, device=DEV, dtype=torch.bfloat16), None, p1, a=pre, act=1,
+                                             seed=s1 if p1 > 0 else None, want_act=True)
+    close(act_k.float(), act.float(), 1e-2, 4e-3)
+    assert torch.equal(act_k == 0, (~m1) | (act_k == 0))
+    assert torch.equal(da == 0, (~m1) | (da == 0))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.15])
+def test_ffn_rows_fused_training_node_gradients(p, monkeypatch):
+    """FfnRowsFn on the fused training forward (bf16 autocast, d_model 256) with dropout live: output and every gradient against
+    torch autograd on the same function with the SAME masks (read back from the dropout stream with the seeds the node drew),
+    in fp64."""
+    import torch.nn as nn
+    from mamba_asr_amd import ops
+    from mamba_asr_amd.modules import Conmamba as CM
+    from mamba_asr_amd.modules import ffn_rows
+    assert ffn_rows.FUSED_TRAIN
+    torch.manual_seed(11)
+    layer = CM.ConmambaEncoderLayer(d_model=256, d_ffn=1024, kernel_size=31, activation=nn.GELU, bias=True, dropout=p, causal=False,
+                                    mamba_config={"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True}).to(DEV)
+    layer.train()
+    mod = layer.ffn_module2
+    with torch.no_grad():
+        for p_ in mod.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    B, T, D, F_ = 3, 50, 256, 1024
+    x = torch.randn(B, T, D, device=DEV)
+    dy = torch.randn(B, T, D, device=DEV)
+    seeds = iter([424242, 171717])
+    drawn = []
+    monkeypatch.setattr(ops, "draw_seed", lambda: (drawn.append(next(seeds)), drawn[-1])[1])
+    xg = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        got = layer._ffn(mod, xg)
+    params = list(mod.parameters())
+    ggot = torch.autograd.grad(got, [xg] + params, dy)
+    monkeypatch.undo()
+    assert len(drawn) == (2 if p > 0 else 0)
+    ln = mod[0]
+    sc = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+    m1 = _drop_masks(ops, B * T, F_, p, drawn[0]).view(B, T, F_).double() * sc if p > 0 else 1.0
+    m2 = _drop_masks(ops, B * T, D, p, drawn[1]).view(B, T, D).double() * sc if p > 0 else 1.0
+    ps = [q.detach().double().requires_grad_(True) for q in params]
+    xr = x.double().requires_grad_(True)
+    # parameters come as (ln.weight, ln.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    lnw, lnb, w1, b1, w2, b2 = ps
+    h = torch.nn.functional.layer_norm(xr, (D,), lnw, lnb, ln.eps)
+    want = xr + 0.5 * ((torch.nn.functional.gelu(h @ w1.t() + b1) * m1) @ w2.t() + b2) * m2
+    gref = torch.autograd.grad(want, [xr] + ps, dy.double())
+    close(got, want.detach(), 2e-2, 1.5e-2)
+    for a_, b_ in zip(ggot, gref):
+        close(a_, b_, 5e-2, 1.5e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_convmod_rows_node_vs_module_tree(dtype, causal):
