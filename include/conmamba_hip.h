@@ -311,7 +311,7 @@ typedef struct cm_scan_cl_bwd_args {
     int64_t z_bs, z_ts;
     int32_t time_chunks;     /* 0: automatic (launches under 512 workgroups are cut along time: adjoint summaries per chunk,
                                 a carry fold, then the full pass per chunk from its carried-in adjoint); 1: never; n: n chunks */
-    int32_t reserved0;
+    int32_t overwrite;       /* 1: dA / ddt_weight / dD / ddelta_bias are written, not accumulated into */
     cm_scan_cl_bwd_dir dir[2];
     void   *stream;
     void   *workspace;       /* cm_scan_cl_bwd_workspace_bytes(args) bytes, 16-byte aligned  */
@@ -363,6 +363,8 @@ typedef struct cm_conv_cl_bwd_args {
     void *stream;
     float *workspace;                                     /* cm_conv_cl_bwd_workspace_floats() floats       */
     int64_t workspace_floats;
+    int32_t overwrite;                                    /* 1: the parameter gradients are written, not accumulated into */
+    int32_t reserved0;
 } cm_conv_cl_bwd_args;
 
 /* CTC loss + gradient (csrc/ctc.hip; replaces torch.nn.functional.ctc_loss behind speechbrain.nnet.losses.ctc_loss, reference
@@ -409,6 +411,8 @@ typedef struct cm_ffn_elem_args {
     void *stream;
     void        *act_out;                     /* backward, optional (act 1, bf16): dropout(GELU(a + bias)) recomputed -- what the
                                                  training forward of cm_ffn_fused fed to its second GEMM                            */
+    int32_t overwrite;                        /* 1: dbias is written, not accumulated into (no memset in front of the call)        */
+    int32_t reserved0;
 } cm_ffn_elem_args;
 
 int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim);
@@ -594,6 +598,8 @@ typedef struct cm_dwconv_cl_args {
     float       *partial;        /* backward workspace */
     int64_t x_bs, x_ts, y_bs, y_ts, dy_bs, dy_ts, dx_bs, dx_ts;
     void *stream;
+    int32_t overwrite;           /* backward: 1 = dweight / dbias are written, not accumulated into */
+    int32_t reserved0;
 } cm_dwconv_cl_args;
 
 int64_t cm_dwconv_cl_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);

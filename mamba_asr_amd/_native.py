@@ -89,7 +89,7 @@ class FfnElemArgs(C.Structure):
     _fields_ = [
         ("rows", i64), ("dim", i32), ("io_dtype", i32), ("act", i32), ("dy_f32", i32),
         ("a", vp), ("bias", fp), ("res", fp), ("y", vp), ("mask", vp), ("dy", vp), ("da", vp), ("dbias", fp), ("dbias_part", fp),
-        ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp), ("act_out", vp),
+        ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp), ("act_out", vp), ("overwrite", i32), ("reserved0", i32),
     ]
 
 
@@ -101,7 +101,7 @@ class ConvClBwdArgs(C.Structure):
         ("dweight_f", fp), ("dbias_f", fp), ("dweight_b", fp), ("dbias_b", fp),
         ("x_bs", i64), ("x_ts", i64), ("duf_bs", i64), ("duf_ts", i64), ("dub_bs", i64), ("dub_ts", i64),
         ("dzf_bs", i64), ("dzf_ts", i64), ("dzb_bs", i64), ("dzb_ts", i64), ("dx_bs", i64), ("dx_ts", i64), ("dz_bs", i64), ("dz_ts", i64),
-        ("stream", vp), ("workspace", fp), ("workspace_floats", i64),
+        ("stream", vp), ("workspace", fp), ("workspace_floats", i64), ("overwrite", i32), ("reserved0", i32),
     ]
 
 
@@ -118,7 +118,7 @@ class ScanClBwdDir(C.Structure):
 class ScanClBwdArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32), ("io_dtype", i32), ("ndir", i32),
-        ("z", vp), ("z_bs", i64), ("z_ts", i64), ("time_chunks", i32), ("reserved0", i32),
+        ("z", vp), ("z_bs", i64), ("z_ts", i64), ("time_chunks", i32), ("overwrite", i32),
         ("dir", ScanClBwdDir * 2),
         ("stream", vp), ("workspace", vp), ("workspace_bytes", i64),
     ]
@@ -172,7 +172,7 @@ class DwconvClArgs(C.Structure):
         ("batch", i32), ("dim", i32), ("seqlen", i32), ("ksize", i32), ("pad_left", i32), ("io_dtype", i32),
         ("x", vp), ("weight", fp), ("bias", fp), ("y", vp), ("dy", vp), ("dx", vp), ("dweight", fp), ("dbias", fp), ("partial", fp),
         ("x_bs", i64), ("x_ts", i64), ("y_bs", i64), ("y_ts", i64), ("dy_bs", i64), ("dy_ts", i64), ("dx_bs", i64), ("dx_ts", i64),
-        ("stream", vp),
+        ("stream", vp), ("overwrite", i32), ("reserved0", i32),
     ]
 
 

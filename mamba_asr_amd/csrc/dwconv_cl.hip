@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256) void dwconv_cl_reduce_kernel(const cm_dwconv_c
 #pragma unroll
     for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x & 31];
     const int c = i / (KMAX + 1), k = i % (KMAX + 1);
-    if (k < p.ksize) p.dweight[c * p.ksize + k] += t;
-    else if (k == KMAX && p.dbias) p.dbias[c] += t;
+    if (k < p.ksize) p.dweight[c * p.ksize + k] = p.overwrite ? t : p.dweight[c * p.ksize + k] + t;
+    else if (k == KMAX && p.dbias) p.dbias[c] = p.overwrite ? t : p.dbias[c] + t;
 }
 
 int check(const cm_dwconv_cl_args &a, const char *what) {

@@ -521,8 +521,7 @@ def bias_act_dropout_bwd(dy, mask, p, a=None, bias=None, act=0, alpha=1.0, out_d
         nws = int(N.lib().cm_bias_act_dropout_bwd_workspace_floats(rows, dim))
         ws = torch.empty((nws + dim,), dtype=torch.float32, device=dy.device)
         dbias = ws[nws:]
-        dbias.zero_()
-        args.dbias, args.dbias_part = _ptr(dbias), _ptr(ws)
+        args.dbias, args.dbias_part, args.overwrite = _ptr(dbias), _ptr(ws), 1
     _launch("cm_bias_act_dropout_bwd", N.lib().cm_bias_act_dropout_bwd, args, units=rows)
     return (da, dbias, act_out) if want_act else (da, dbias)
 
@@ -553,7 +552,7 @@ def bias_glu_bwd(dy, a, bias):
     nws = int(N.lib().cm_bias_act_dropout_bwd_workspace_floats(rows, d))
     ws = torch.empty((nws + 2 * d,), dtype=torch.float32, device=dy.device)
     dbias = ws[nws:]
-    dbias.zero_()
+    args.overwrite = 1
     args.a, args.bias, args.dy, args.da, args.dbias, args.dbias_part = _ptr(a), _ptr(bs), _ptr(dy), _ptr(da), _ptr(dbias), _ptr(ws)
     _launch("cm_bias_act_dropout_bwd", N.lib().cm_bias_act_dropout_bwd, args, units=rows)
     return da, dbias
@@ -636,8 +635,9 @@ def conv_cl_bwd(x, weight_f, bias_f, du_f, weight_b=None, bias_b=None, du_b=None
     a.batch, a.seqlen, a.dim, a.width, a.io_dtype = b, l, d, wf.shape[1], _DT[x.dtype]
     a.x, a.weight_f, a.bias_f, a.weight_b, a.bias_b = _ptr(x), _ptr(wf), _ptr(bf), _ptr(wb), _ptr(bb)
     a.du_f, a.du_b, a.dz_f, a.dz_b, a.dx, a.dz = _ptr(du_f), _ptr(du_b), _ptr(dz_f), _ptr(dz_b), _ptr(dx), _ptr(dz)
-    # the kernel writes contiguous (dim, 4) / (dim) tensors: hand it contiguous staging slices of one zeroed buffer
-    flat = torch.zeros((2 * d * (kw + 1),), dtype=torch.float32, device=dev)
+    # the kernel writes contiguous (dim, 4) / (dim) tensors: hand it contiguous staging slices of one buffer (overwrite: no memset)
+    flat = torch.empty((2 * d * (kw + 1),), dtype=torch.float32, device=dev)
+    a.overwrite = 1
     dwf, dwb_ = flat[:d * kw].view(d, kw), flat[d * kw:2 * d * kw].view(d, kw)
     dbf_, dbb_ = flat[2 * d * kw:2 * d * kw + d], flat[2 * d * kw + d:]
     dbf = dbf_ if bf is not None else None
@@ -709,9 +709,10 @@ def scan_cl_bwd(directions, z, time_chunks=0):
         dx = dd.get("dxdbl") if dd.get("dxdbl") is not None else torch.empty((b, l, pad + 32), dtype=u.dtype, device=u.device)
         for t, nm in ((du, "du"), (dz, "dz"), (dx, "dxdbl")):
             _rows_ok(t, nm)
-        if i == 0:                                            # one memset for every accumulated-into gradient of the launch
+        if i == 0:                                            # one buffer for every parameter gradient of the launch (overwrite: no memset)
             npar = d * (16 + pad + 2)
-            zeros = torch.zeros((len(directions) * npar,), dtype=torch.float32, device=u.device)
+            zeros = torch.empty((len(directions) * npar,), dtype=torch.float32, device=u.device)
+            a.overwrite = 1
         zp = zeros[i * npar:(i + 1) * npar]
         dA, dW = zp[:16 * d].view(d, 16), zp[16 * d:(16 + pad) * d].view(d, pad)
         dD = zp[(16 + pad) * d:(17 + pad) * d] if D is not None else None
@@ -951,8 +952,9 @@ def dwconv_cl_bwd(x, weight, dy, has_bias=True, pad_left=None):
     if dy.dtype != x.dtype or dy.shape != x.shape:
         raise RuntimeError("dwconv_cl_bwd: dy must match x in shape and dtype")
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    dw = torch.zeros_like(w)
-    db = torch.zeros((x.shape[2],), dtype=torch.float32, device=x.device) if has_bias else None
+    dw = torch.empty_like(w)
+    db = torch.empty((x.shape[2],), dtype=torch.float32, device=x.device) if has_bias else None
+    a.overwrite = 1
     part = torch.empty((N.lib().cm_dwconv_cl_workspace_floats(x.shape[0], x.shape[1], x.shape[2]),), dtype=torch.float32, device=x.device)
     a.dy, a.dy_bs, a.dy_ts, a.dx, a.dx_bs, a.dx_ts = _ptr(dy), dy.stride(0), dy.stride(1), _ptr(dx), dx.stride(0), dx.stride(1)
     a.dweight, a.dbias, a.partial = _ptr(dw), _ptr(db), _ptr(part)
