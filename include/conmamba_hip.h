@@ -424,6 +424,35 @@ int cm_bias_act_dropout_bwd(const cm_ffn_elem_args *args);
  * CM_F32 or CM_BF16; n a multiple of 8 (bf16 in) / 4 (fp32 in); 16-byte aligned. */
 int cm_sum_leading(const void *in, void *out, int32_t nbatch, int64_t n, int32_t in_dtype, int32_t out_dtype, void *stream);
 
+/* Reflect padding by `pad` of the time and frequency axes of a dense channels-last (batch, time, freq, channels) tensor -- the 'same'
+ * padding in front of every Conv2d of the reference's front end (speechbrain ConvolutionFrontEnd, hparams/CTC/conmamba_large.yaml:187-194).
+ *   backward = 0: dst (batch, time + 2 pad, freq + 2 pad, channels) = padded src
+ *   backward = 1: src is the padded tensor's gradient, dst (batch, time, freq, channels) its fold back onto the source positions
+ * dtype CM_F32 / CM_BF16; 1 <= pad, 2 pad < time, freq. */
+int cm_reflect_pad_tf(const void *src, void *dst, int32_t batch, int32_t time, int32_t freq, int32_t channels, int32_t pad,
+                      int32_t dtype, int32_t backward, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight gradient of a Linear: out (m, n) fp32 = sum over rows k of a[k, :m]^T b[k, :n]  (dW = dY^T X; the reference leaves it to
+ * autograd: one GEMM with K = batch x time per Linear, modules/Conmamba.py:597-650, selective_scan_interface.py:262-284).
+ * a (rows, m), b (rows, n) bf16, row strides lda / ldb in elements (multiples of 8); m, n multiples of 128.  Split over row chunks into
+ * workspace (cm_wgrad_workspace_floats floats), folded in a fixed order: deterministic.  out is WRITTEN.
+ * ------------------------------------------------------------------------------------- */
+typedef struct cm_wgrad_args {
+    int32_t rows, m, n;
+    int32_t variant;             /* 0: the library picks; 1: tiles travel through registers; 2: global -> LDS directly (LDS-DMA) */
+    const void *a, *b;
+    int64_t lda, ldb;
+    float *out;
+    float *workspace;
+    int64_t workspace_floats;
+    void *stream;
+} cm_wgrad_args;
+
+int cm_wgrad_supported(int32_t rows, int32_t m, int32_t n);
+int64_t cm_wgrad_workspace_floats(int32_t rows, int32_t m, int32_t n);
+int cm_wgrad_bf16(const cm_wgrad_args *args);
+
 int64_t cm_conv_cl_bwd_workspace_floats(int32_t batch, int32_t seqlen, int32_t dim);
 int cm_conv_cl_bwd(const cm_conv_cl_bwd_args *args);
 

@@ -93,6 +93,13 @@ class FfnElemArgs(C.Structure):
     ]
 
 
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("rows", i32), ("m", i32), ("n", i32), ("variant", i32), ("a", vp), ("b", vp), ("lda", i64), ("ldb", i64),
+        ("out", fp), ("workspace", fp), ("workspace_floats", i64), ("stream", vp),
+    ]
+
+
 class ConvClBwdArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("width", i32), ("io_dtype", i32), ("pad_", i32),
@@ -285,6 +292,10 @@ SYMBOLS = [
     ("cm_scan_cl_fwd_auto_chunks", i32, [i32, i32, i32, i32]),
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
     ("cm_scan_cl_bwd_auto_chunks", C.c_int, [C.c_int] * 4),
+    ("cm_reflect_pad_tf", C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    ("cm_wgrad_supported", C.c_int, [i32, i32, i32]),
+    ("cm_wgrad_workspace_floats", C.c_int64, [i32, i32, i32]),
+    ("cm_wgrad_bf16", C.c_int, [C.POINTER(WgradArgs)]),
     ("cm_scan_cl_bwd", C.c_int, [C.POINTER(ScanClBwdArgs)]),
     ("cm_conv_cl_fwd", C.c_int, [C.POINTER(ConvClArgs)]),
     ("cm_sum_leading", C.c_int, [vp, vp, i32, i64, i32, i32, vp]),

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__res
     }
 }
 
-constexpr int ROWS_PER_WG = 64;
+constexpr int ROWS_PER_WG = 16;     // 64: 500 workgroups at 32 k rows = two waves per SIMD, each walking 32 dependent row passes (75 us for 268 MB)
 
 int check(const cm_ffn_elem_args &a, const char *what) {
     CM_REQUIRE(a.rows > 0 && a.dim > 0, CM_EINVAL, "%s: bad sizes", what);

@@ -64,14 +64,14 @@ class ConvModuleRowsFn(torch.autograd.Function):
             dout2 = dout2.float()
         da_l, db_l = ops.bias_act_dropout_bwd(dout2, m, p, act=0, out_dtype=cdt)
         dg = torch.mm(da_l, ops.cast_cached(lw, cdt))
-        dlw = ops.sum_leading(torch.bmm(da_l.view(B, T, D).transpose(1, 2), g.view(B, T, D)))
+        dlw = ops.wgrad(da_l.view(B * T, D), g.view(B * T, D), nbatch=B)
         dy2, _ = ops.bias_act_dropout_bwd(dg, None, 0.0, a=y2, act=1, want_dbias=False)
         dcv, dln2w, dln2b = ops.layernorm_bwd(dy2, cvs, st2, ln2w, eps2)
         dgl, dcw, dcb = ops.dwconv_cl_bwd(gl.view(B, T, D), cw, dcv.view(B, T, D), True, pad_left)
         da_pw, dpwb = ops.bias_glu_bwd(dgl.reshape(B * T, D), a_pw, pwb)
         wpw = ops.cast_cached(pww, cdt).view(2 * D, D)
         dh = torch.mm(da_pw, wpw)
-        dpww = ops.sum_leading(torch.bmm(da_pw.view(B, T, 2 * D).transpose(1, 2), h.view(B, T, D))).view(pww.shape)
+        dpww = ops.wgrad(da_pw.view(B * T, 2 * D), h.view(B * T, D), nbatch=B).view(pww.shape)
         dx, dln1w, dln1b = ops.layernorm_bwd(dh, x2s, st1, ln1w, eps1, dres=dout2)     # dx = dout + LayerNorm'(dh) in one pass
         dx = dx.view(B, T, D)
         return (dx, dln1w, dln1b, dpww, dpwb, dcw.reshape(cw.shape), dcb, dln2w, dln2b, dlw, db_l, None, None, None, None)

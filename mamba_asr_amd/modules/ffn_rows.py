@@ -88,10 +88,10 @@ class FfnRowsFn(torch.autograd.Function):
         w1c, w2c = ops.cast_cached(w1, cdt), ops.cast_cached(w2, cdt)
         da2, db2 = ops.bias_act_dropout_bwd(dout2, m2, p2, act=0, alpha=alpha, out_dtype=cdt)
         dg = torch.mm(da2, w2c)
-        dw2 = ops.sum_leading(torch.bmm(da2.view(B, T, D).transpose(1, 2), g.view(B, T, F_)))
+        dw2 = ops.wgrad(da2.view(B * T, D), g.view(B * T, F_), nbatch=B)
         da1, db1 = ops.bias_act_dropout_bwd(dg, m1, p1, a=a1, bias=b1, act=1)
         dh = torch.mm(da1, w1c)
-        dw1 = ops.sum_leading(torch.bmm(da1.view(B, T, F_).transpose(1, 2), h.view(B, T, D)))
+        dw1 = ops.wgrad(da1.view(B * T, F_), h.view(B * T, D), nbatch=B)
         dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2s, stats, lnw, eps, dres=dout2)       # dx = dout + LayerNorm'(dh) in one pass
         dx = dx.view(B, T, D)
         return dx, dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None
@@ -111,9 +111,9 @@ def _backward_fused(ctx, dout):
     dg = torch.mm(da2, w2c)
     # pre already holds the bias; one pass gives the first GEMM's output gradient AND the activation the forward's second GEMM saw
     da1, db1, g = ops.bias_act_dropout_bwd(dg, None, p1, a=pre, act=1, seed=s1 if p1 > 0.0 else None, want_act=True)
-    dw2 = ops.sum_leading(torch.bmm(da2.view(B, T, D).transpose(1, 2), g.view(B, T, F_)))
+    dw2 = ops.wgrad(da2.view(B * T, D), g.view(B * T, F_), nbatch=B)
     dh = torch.mm(da1, w1c)
-    dw1 = ops.sum_leading(torch.bmm(da1.view(B, T, F_).transpose(1, 2), h.view(B, T, D)))
+    dw1 = ops.wgrad(da1.view(B * T, F_), h.view(B * T, D), nbatch=B)
     dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2, stats, lnw, eps, dres=dout2)
     return dx.view(B, T, D), dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None
 

@@ -161,7 +161,7 @@ class MixerRowsFn(torch.autograd.Function):
         x, z = xz[:, :, :E], xz[:, :, E:]
         # out_proj: every direction sees the same gradient, dmix = dY (scale W_out)
         dmix = torch.mm(dY.view(B * T, D), dv.w_out).view(B, T, E)
-        d_out_cat = ops.sum_leading(torch.bmm(dY.transpose(1, 2), ycat))               # (D, ndir * E): per utterance, then summed (fp32)
+        d_out_cat = ops.wgrad(dY.view(B * T, D), ycat.view(B * T, ndir * E), nbatch=B)    # (D, ndir * E), fp32, fixed summation order
         d_out_w = d_out_cat[:, :E] if ndir == 1 else d_out_cat[:, :E] + d_out_cat[:, E:]
         d_out_w = d_out_w * scale
         # scan backward, all directions in one launch
@@ -200,7 +200,7 @@ class MixerRowsFn(torch.autograd.Function):
         if ln is not None:                                                              # dx = dY + LayerNorm'(dh) in one pass
             d_hidden, dlw, dlb = ops.layernorm_bwd(d_hidden.view(B * T, D), x2s, stats, ln.weight, ln.eps, dres=dres)
             d_hidden, dln = d_hidden.view(B, T, D), (dlw, dlb)
-        d_in_w = ops.sum_leading(torch.bmm(dxz.transpose(1, 2), h2))                   # (2E, D)
+        d_in_w = ops.wgrad(dxz.view(B * T, 2 * E), h2.view(B * T, D), nbatch=B)            # (2E, D)
         for i, s in enumerate(sfx):
             r = res[i]
             dxw = torch.cat([dxr[i][:R], dxr[i][P:]], dim=0)                            # back to x_proj's (R + 32, E) rows

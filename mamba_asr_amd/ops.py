@@ -61,6 +61,60 @@ def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+def reflect_pad_tf(x, pad, backward=False, shape=None):
+    """Reflect padding of the time and frequency axes of a channels-last (batch, time, freq, channels) tensor (cm_reflect_pad_tf).
+    backward: x is the padded tensor's gradient and ``shape`` the source's shape -> the gradient folded back."""
+    _dev_check(x)
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("reflect_pad_tf: expected a contiguous (batch, time, freq, channels) fp32 / bf16 tensor")
+    if backward:
+        b, t, f, c = shape
+        if tuple(x.shape) != (b, t + 2 * pad, f + 2 * pad, c):
+            raise RuntimeError("reflect_pad_tf: gradient shape does not match the padded source shape")
+        out = torch.empty((b, t, f, c), dtype=x.dtype, device=x.device)
+    else:
+        b, t, f, c = x.shape
+        out = torch.empty((b, t + 2 * pad, f + 2 * pad, c), dtype=x.dtype, device=x.device)
+    rc = N.lib().cm_reflect_pad_tf(_ptr(x), _ptr(out), b, t, f, c, int(pad), _DT[x.dtype], int(bool(backward)), _stream())
+    N.check(rc, "cm_reflect_pad_tf")
+    return out
+
+
+class ReflectPadTfFn(torch.autograd.Function):
+    """autograd node over cm_reflect_pad_tf (torch: F.pad(..., mode='reflect') on the 5-d view, 448 / 851 us at block 2's size)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad, ctx.shape = pad, tuple(x.shape)
+        return reflect_pad_tf(x if x.is_contiguous() else x.contiguous(), pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return reflect_pad_tf(dy if dy.is_contiguous() else dy.contiguous(), ctx.pad, backward=True, shape=ctx.shape), None
+
+
+def wgrad(a, b, nbatch=None, variant=0):
+    """dW (M, N) fp32 = a^T b for a (rows, M), b (rows, N): the weight gradient of a Linear from its output gradient and its input.
+    bf16 operands with M, N multiples of 128: cm_wgrad_bf16 (split over row chunks, fixed-order fold).  Otherwise ``nbatch``
+    batched GEMMs over equal row chunks folded by cm_sum_leading (fp32 accumulation in a fixed order either way)."""
+    _dev_check(a, b)
+    rows, M = a.shape
+    Nn = b.shape[1]
+    if (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+            and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and N.lib().cm_wgrad_supported(rows, M, Nn)):
+        args = N.WgradArgs()
+        args.rows, args.m, args.n, args.variant = rows, M, Nn, int(variant)   # 0: the library picks; 1 registers, 2 LDS-DMA staging
+        args.a, args.b, args.lda, args.ldb = _ptr(a), _ptr(b), a.stride(0), b.stride(0)
+        nws = int(N.lib().cm_wgrad_workspace_floats(rows, M, Nn))
+        ws = torch.empty((nws,), dtype=torch.float32, device=a.device)
+        out = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
+        args.out, args.workspace, args.workspace_floats, args.stream = _ptr(out), _ptr(ws), nws, _stream()
+        _launch("cm_wgrad_bf16", N.lib().cm_wgrad_bf16, args, units=rows)
+        return out
+    nb = nbatch if (nbatch and rows % nbatch == 0) else 1
+    return sum_leading(torch.bmm(a.view(nb, rows // nb, M).transpose(1, 2), b.view(nb, rows // nb, Nn)))
+
+
 def pack_cached(p: torch.Tensor) -> "PackedWeight":
     """p (2-D parameter) as a bf16 PackedWeight (cm_ffn_fused's fragment-tiled image), cached like cast_cached."""
     c = getattr(p, "_cm_pack", None)

@@ -448,7 +448,11 @@ class _ConvLayer(nn.Module):
         # reflect padding of the time and frequency axes ON the channels-last tensor (as a 3-d reflection pad of
         # (t, f, c) with no padding on c): torch's 2-d reflection pad wants an NCHW-contiguous input, which cost a transposing
         # copy of the activations into NCHW and another one back, forward and backward
-        y = F.pad(x.unsqueeze(0), (0, 0, p, p, p, p), mode="reflect").squeeze(0).permute(0, 3, 1, 2)
+        from . import ops
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and 2 * p < min(x.shape[1], x.shape[2]) and p >= 1:
+            y = ops.ReflectPadTfFn.apply(x, p).permute(0, 3, 1, 2)             # cm_reflect_pad_tf, forward and backward
+        else:
+            y = F.pad(x.unsqueeze(0), (0, 0, p, p, p, p), mode="reflect").squeeze(0).permute(0, 3, 1, 2)
         y = self.conv(y).permute(0, 2, 3, 1)                       # (b, t', f', c) view, contiguous for channels_last
         y = self.act(self.norm(y))
         if self.training and self.drop.p > 0:

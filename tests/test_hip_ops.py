@@ -644,3 +644,53 @@ def test_bimamba_layer_gradients_are_bit_reproducible():
 
     g1, g2 = run(), run()
     assert all(torch.equal(a_, b_) for a_, b_ in zip(g1, g2))
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 7, 1), (3, 40, 20, 64), (1, 5, 6, 3), (2, 11, 8, 8), (2, 6, 5, 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pad", [1, 2])
+def test_reflect_pad_tf_forward_and_backward(shape, dtype, pad):
+    """cm_reflect_pad_tf against torch's reflection pad on the same channels-last tensor (the padding of the front end's Conv2d
+    blocks): forward bit-exact; backward = autograd's fold of the padded gradient (sums of up to four values)."""
+    from mamba_asr_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    x = torch.randn(*shape, generator=g).to(dtype).to(DEV).requires_grad_(True)
+    ref = torch.nn.functional.pad(x.unsqueeze(0), (0, 0, pad, pad, pad, pad), mode="reflect").squeeze(0)
+    got = ops.ReflectPadTfFn.apply(x, pad)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    dy = torch.randn(ref.shape, generator=g).to(dtype).to(DEV)
+    (gref,) = torch.autograd.grad(ref, x, dy)
+    (ggot,) = torch.autograd.grad(got, x, dy)
+    if dtype == torch.float32:
+        torch.testing.assert_close(ggot, gref, rtol=1e-6, atol=1e-6)
+    else:
+        torch.testing.assert_close(ggot.float(), gref.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,m,n", [(64, 128, 128), (1000, 256, 128), (777, 128, 384), (4100, 1024, 256), (32000, 256, 1024)])
+@pytest.mark.parametrize("strided", [False, True])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_wgrad_bf16_against_fp64(rows, m, n, strided, variant):
+    """cm_wgrad_bf16 (split-K over row chunks, both operands transposed on the way out of LDS) against a^T b in fp64 on the same
+    bf16 values; operands as column slices of wider tensors (the gradients of the concatenated BiMamba tensors); run twice: same bits."""
+    from mamba_asr_amd import ops
+    g = torch.Generator().manual_seed(rows + m + n)
+    wa, wb = (m + 64, n + 128) if strided else (m, n)
+    A = torch.randn(rows, wa, generator=g).bfloat16().to(DEV)
+    B = torch.randn(rows, wb, generator=g).bfloat16().to(DEV)
+    a, b = (A[:, 64:], B[:, 128:]) if strided else (A, B)
+    got = ops.wgrad(a, b, variant=variant)
+    ref = (a.double().t() @ b.double())
+    err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
+    assert got.shape == (m, n) and got.dtype == torch.float32 and err < 2e-6, err
+    assert torch.equal(got, ops.wgrad(a, b, variant=variant))
+
+
+def test_wgrad_falls_back_to_batched_gemms_for_other_shapes():
+    from mamba_asr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(600, 48, generator=g).bfloat16().to(DEV)
+    b = torch.randn(600, 512, generator=g).bfloat16().to(DEV)
+    got = ops.wgrad(a, b, nbatch=6)
+    ref = a.double().t() @ b.double()
+    assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-2      # per-chunk products are rounded to bf16

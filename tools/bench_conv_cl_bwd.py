@@ -1,6 +1,6 @@
 """cm_conv_cl_bwd (both directions' causal conv + SiLU backward, dz = dz_f + dz_b) at ConMamba-large training sizes."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mamba_asr_amd import ops
 

@@ -3,7 +3,7 @@
 torch.profiler with Python stacks; for every aten op matching PATTERN (default: fill / zero / copy), the count per innermost
 repository frame."""
 import collections, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import ProfilerActivity, profile
 
