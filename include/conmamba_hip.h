@@ -838,6 +838,33 @@ typedef struct cm_ffn_args {
 
 int cm_ffn_fused(const cm_ffn_args *args);
 
+/* The data-gradient chain of the same module's backward (what autograd does over modules/Conmamba.py:597-617 with two Dropout, two
+ * addmm and one GELU backward), for the forward cm_ffn_fused's training variant ran (same dropout seeds):
+ *   da2 = alpha * dout * keep2 / (1 - p2);  dg = da2 @ W2;  da1 = dg * keep1 / (1 - p1) * GELU'(pre);  act = drop1(GELU(pre));
+ *   dh = da1 @ W1;  db2 = column sums of da2;  db1 = column sums of da1 (fixed order: deterministic)
+ * w2t = W2^T (hidden, 256), w1t = W1^T (256, hidden): bf16 in cm_ffn_pack_weights' image.  da2 / da1 / act are stored for the weight
+ * gradients (cm_wgrad_bf16), dh (bf16) for the LayerNorm backward in front of the module.  d_model 256, hidden a multiple of 256. */
+typedef struct cm_ffn_bwd_args {
+    int32_t rows, dim, hidden, reserved0;
+    const float *dout;                  /* (rows, 256) fp32: gradient of the module's output (the residual stream)          */
+    const void  *w2t, *w1t;
+    const void  *pre;                   /* (rows, hidden) bf16: cm_ffn_args.pre_out of the forward                          */
+    void *da2;                          /* (rows, 256) bf16 out                                                             */
+    void *da1, *act;                    /* (rows, hidden) bf16 out                                                          */
+    void *dh;                           /* (rows, 256) bf16 out                                                             */
+    float *db1, *db2;                   /* (hidden), (256) fp32 out (written)                                               */
+    float alpha, p1, p2;
+    float reserved1;
+    uint64_t seed1, seed2;
+    float *workspace;                   /* cm_ffn_bwd_workspace_floats(rows, hidden) floats                                  */
+    int64_t workspace_floats;
+    void *stream;
+    float *db1_part, *db2_part;         /* internal (set by the library)                                                    */
+} cm_ffn_bwd_args;
+
+int64_t cm_ffn_bwd_workspace_floats(int32_t rows, int32_t hidden);
+int cm_ffn_bwd_fused(const cm_ffn_bwd_args *args);
+
 /* ---------------------------------------------------------------------------------------
  * Fbank back end (speechbrain Fbank semantics as used at reference train_CTC.py:285 and configured at
  * hparams/CTC/conmamba_large.yaml:322-326): STFT (re, im) -> power -> triangular mel filterbank -> 10*log10 with

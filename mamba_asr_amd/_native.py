@@ -260,6 +260,15 @@ class FfnArgs(C.Structure):
     ]
 
 
+class FfnBwdArgs(C.Structure):
+    _fields_ = [
+        ("rows", i32), ("dim", i32), ("hidden", i32), ("reserved0", i32), ("dout", fp), ("w2t", vp), ("w1t", vp), ("pre", vp),
+        ("da2", vp), ("da1", vp), ("act", vp), ("dh", vp), ("db1", fp), ("db2", fp),
+        ("alpha", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("reserved1", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
+        ("workspace", fp), ("workspace_floats", i64), ("stream", vp), ("db1_part", fp), ("db2_part", fp),
+    ]
+
+
 class FbankArgs(C.Structure):
     _fields_ = [
         ("batch", i32), ("n_freq", i32), ("frames", i32), ("n_mels", i32),
@@ -293,6 +302,8 @@ SYMBOLS = [
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
     ("cm_scan_cl_bwd_auto_chunks", C.c_int, [C.c_int] * 4),
     ("cm_reflect_pad_tf", C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    ("cm_ffn_bwd_workspace_floats", C.c_int64, [i32, i32]),
+    ("cm_ffn_bwd_fused", C.c_int, [C.POINTER(FfnBwdArgs)]),
     ("cm_wgrad_supported", C.c_int, [i32, i32, i32]),
     ("cm_wgrad_workspace_floats", C.c_int64, [i32, i32, i32]),
     ("cm_wgrad_bf16", C.c_int, [C.POINTER(WgradArgs)]),

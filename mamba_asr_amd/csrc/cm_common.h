@@ -153,6 +153,35 @@ __device__ __forceinline__ uint32_t cm_gelu_drop_bf16_pack2(float a, float b, ui
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2b));
 }
 
+typedef float cm_v2f __attribute__((ext_vector_type(2)));
+// the same derivative AND dropout(GELU(x)) as cm_gelu_drop_bf16_pack2 gives it (same operations in the same order: same bits), from
+// one exponential and one reciprocal per element
+__device__ __forceinline__ cm_v2f cm_gelu_grad_and_act_bf16_2(cm_v2f x, uint32_t keep_a, uint32_t keep_b, float scale, uint32_t &act) {
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    constexpr float c2 = 7.03033577e-04f * CM_LOG2E, c1 = -7.40112920e-02f * CM_LOG2E, c0 = -1.59501577f * CM_LOG2E;
+    cm_v2f x2 = x * x;
+    x2 = cm_v2f{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    cm_v2f q = __builtin_elementwise_fma(x2, cm_v2f{c2, c2}, cm_v2f{c1, c1});
+    q = __builtin_elementwise_fma(x2, q, cm_v2f{c0, c0});
+    const cm_v2f t2 = __builtin_elementwise_fma(x2, cm_v2f{2.f * c2, 2.f * c2}, cm_v2f{c1, c1});
+    const cm_v2f de = __builtin_elementwise_fma(x2 + x2, t2, q);
+    const cm_v2f e = x * q;
+    const cm_v2f d = cm_v2f{cm_exp2(e.x), cm_exp2(e.y)} + cm_v2f{1.0f, 1.0f};
+    const cm_v2f s = {cm_rcp(d.x), cm_rcp(d.y)};
+    const cm_v2f m = {keep_a ? scale : 0.f, keep_b ? scale : 0.f};
+    const cm_v2f r = (x * s) * m;
+    act = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2b));
+    const cm_v2f ss = __builtin_elementwise_fma(-s, s, s);
+    return __builtin_elementwise_fma(x * ss, de * cm_v2f{-CM_LN2, -CM_LN2}, s);
+}
+// d/dx of 0.5 x erfc(-x / sqrt 2)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = cm_gelu(x) / (x == 0.f ? 1.f : x);            // Phi(x) for x != 0
+    const float phi = 0.3989422804014327f * cm_exp2(-0.5f * CM_LOG2E * x * x);
+    return (x == 0.f ? 0.5f : cdf) + x * phi;
+}
+
+
 // softplus, beta=1, threshold=20 (torch default; reference selective_scan_interface.py:112).
 // For x < -15, log1p(e^x) == e^x to fp32 precision; using it avoids the 1+tiny cancellation.
 __device__ __forceinline__ float cm_softplus(float x) {

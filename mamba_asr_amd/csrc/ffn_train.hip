@@ -33,33 +33,6 @@ __device__ __forceinline__ v2f gelu_grad_bf16_2(v2f x) {
     return __builtin_elementwise_fma(x * ss, de * v2f{-CM_LN2, -CM_LN2}, s);
 }
 
-// the same derivative AND dropout(GELU(x)) as cm_gelu_drop_bf16_pack2 gives it (same operations in the same order: same bits), from
-// one exponential and one reciprocal per element
-__device__ __forceinline__ v2f gelu_grad_and_act_bf16_2(v2f x, uint32_t keep_a, uint32_t keep_b, float scale, uint32_t &act) {
-    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
-    constexpr float c2 = 7.03033577e-04f * CM_LOG2E, c1 = -7.40112920e-02f * CM_LOG2E, c0 = -1.59501577f * CM_LOG2E;
-    v2f x2 = x * x;
-    x2 = v2f{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
-    v2f q = __builtin_elementwise_fma(x2, v2f{c2, c2}, v2f{c1, c1});
-    q = __builtin_elementwise_fma(x2, q, v2f{c0, c0});
-    const v2f t2 = __builtin_elementwise_fma(x2, v2f{2.f * c2, 2.f * c2}, v2f{c1, c1});
-    const v2f de = __builtin_elementwise_fma(x2 + x2, t2, q);
-    const v2f e = x * q;
-    const v2f d = v2f{cm_exp2(e.x), cm_exp2(e.y)} + v2f{1.0f, 1.0f};
-    const v2f s = {cm_rcp(d.x), cm_rcp(d.y)};
-    const v2f m = {keep_a ? scale : 0.f, keep_b ? scale : 0.f};
-    const v2f r = (x * s) * m;
-    act = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, v2b));
-    const v2f ss = __builtin_elementwise_fma(-s, s, s);
-    return __builtin_elementwise_fma(x * ss, de * v2f{-CM_LN2, -CM_LN2}, s);
-}
-// d/dx of 0.5 x erfc(-x / sqrt 2)
-__device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = cm_gelu(x) / (x == 0.f ? 1.f : x);            // Phi(x) for x != 0
-    const float phi = 0.3989422804014327f * cm_exp2(-0.5f * CM_LOG2E * x * x);
-    return (x == 0.f ? 0.5f : cdf) + x * phi;
-}
-
 template <typename T> __device__ __forceinline__ void ld_vec(const T *p, float *f);
 template <> __device__ __forceinline__ void ld_vec<cm_bf16>(const cm_bf16 *p, float *f) {
     const uint4 v = *reinterpret_cast<const uint4 *>(p);
@@ -153,7 +126,7 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
                     for (int k = 0; k < 8; k += 2) {
                         const uint32_t ka = (keep8 >> k) & 1u, kb = (keep8 >> (k + 1)) & 1u;
                         // with act_out: also the activation the forward fed to the next GEMM, from the same exponential
-                        const v2f gg = p.act_out ? gelu_grad_and_act_bf16_2(v2f{a[k], a[k + 1]}, ka, kb, dscale, o[k / 2])
+                        const v2f gg = p.act_out ? cm_gelu_grad_and_act_bf16_2(v2f{a[k], a[k + 1]}, ka, kb, dscale, o[k / 2])
                                                  : gelu_grad_bf16_2(v2f{a[k], a[k + 1]});
                         da[k] = ka ? dy[k] * scale * gg.x : 0.f;
                         da[k + 1] = kb ? dy[k + 1] * scale * gg.y : 0.f;

@@ -27,6 +27,8 @@ from .. import ops
 # CM_FFN_ROWS=0: the module tree runs as written (torch element-wise kernels between the GEMMs)
 ENABLED = os.environ.get("CM_FFN_ROWS", "1") == "1"
 FUSED_TRAIN = os.environ.get("CM_FFN_FUSED_TRAIN", "1") == "1"
+# the backward's data-gradient chain as one kernel (cm_ffn_bwd_fused); CM_FFN_FUSED_BWD=0 = dgrad GEMMs + element-wise kernels
+FUSED_BWD = os.environ.get("CM_FFN_FUSED_BWD", "1") == "1"
 
 
 def _fused_ok(cdt, D, F_, rows):
@@ -106,13 +108,17 @@ def _backward_fused(ctx, dout):
     dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
     if dout2.dtype != torch.float32:
         dout2 = dout2.float()
-    w1c, w2c = ops.cast_cached(w1, cdt), ops.cast_cached(w2, cdt)
-    da2, db2 = ops.bias_act_dropout_bwd(dout2, None, p2, act=0, alpha=alpha, out_dtype=cdt, seed=s2 if p2 > 0.0 else None)
-    dg = torch.mm(da2, w2c)
-    # pre already holds the bias; one pass gives the first GEMM's output gradient AND the activation the forward's second GEMM saw
-    da1, db1, g = ops.bias_act_dropout_bwd(dg, None, p1, a=pre, act=1, seed=s1 if p1 > 0.0 else None, want_act=True)
+    if FUSED_BWD:
+        # dout -> da2 -> dg -> da1 (+ the recomputed activation) -> dh and both bias gradients: one kernel, the hidden tile stays in LDS
+        da2, da1, g, dh, db1, db2 = ops.ffn_bwd_fused(dout2, ops.pack_cached_t(w2), ops.pack_cached_t(w1), pre, alpha, p1, p2, s1, s2)
+    else:
+        w1c, w2c = ops.cast_cached(w1, cdt), ops.cast_cached(w2, cdt)
+        da2, db2 = ops.bias_act_dropout_bwd(dout2, None, p2, act=0, alpha=alpha, out_dtype=cdt, seed=s2 if p2 > 0.0 else None)
+        dg = torch.mm(da2, w2c)
+        # pre already holds the bias; one pass gives the first GEMM's output gradient AND the activation the forward's second GEMM saw
+        da1, db1, g = ops.bias_act_dropout_bwd(dg, None, p1, a=pre, act=1, seed=s1 if p1 > 0.0 else None, want_act=True)
+        dh = torch.mm(da1, w1c)
     dw2 = ops.wgrad(da2.view(B * T, D), g.view(B * T, F_), nbatch=B)
-    dh = torch.mm(da1, w1c)
     dw1 = ops.wgrad(da1.view(B * T, F_), h.view(B * T, D), nbatch=B)
     dx, dlnw, dlnb = ops.layernorm_bwd(dh, x2, stats, lnw, eps, dres=dout2)
     return dx.view(B, T, D), dlnw, dlnb, dw1, db1, dw2, db2, None, None, None, None

@@ -129,6 +129,50 @@ def pack_cached(p: torch.Tensor) -> "PackedWeight":
     return pw
 
 
+def pack_cached_t(p: torch.Tensor) -> "PackedWeight":
+    """p^T as a bf16 PackedWeight (the "weights" of cm_ffn_bwd_fused's two GEMMs), cached like cast_cached."""
+    c = getattr(p, "_cm_pack_t", None)
+    key = (p._version, p.data_ptr())
+    if c is not None and c[0] == key and c[1].data.device == p.device:
+        return c[1]
+    pw = PackedWeight(cast_cached(p, torch.bfloat16).t().contiguous())
+    try:
+        p._cm_pack_t = (key, pw)
+    except (AttributeError, RuntimeError):
+        pass
+    return pw
+
+
+def ffn_bwd_fused(dout, w2t, w1t, pre, alpha, p1, p2, seed1, seed2):
+    """The data-gradient chain of a feed-forward module's backward in one kernel (cm_ffn_bwd_fused), for the forward
+    ffn_fused(..., train=(p1, p2, seed1, seed2)) ran.  dout (rows, 256) fp32; w2t / w1t PackedWeight of W2^T (hidden, 256) /
+    W1^T (256, hidden); pre (rows, hidden) bf16.  -> (da2, da1, act, dh, db1, db2): bf16 (rows, 256) / (rows, hidden) x 2 /
+    (rows, 256), fp32 (hidden) / (256)."""
+    _dev_check(dout, pre)
+    rows, d = dout.shape
+    hidden = pre.shape[1]
+    if dout.dtype != torch.float32 or not dout.is_contiguous() or pre.dtype != torch.bfloat16 or not pre.is_contiguous() or pre.shape[0] != rows:
+        raise RuntimeError("ffn_bwd_fused: dout must be contiguous fp32 (rows, 256), pre contiguous bf16 (rows, hidden)")
+    if w2t.shape != (hidden, d) or w1t.shape != (d, hidden):
+        raise RuntimeError("ffn_bwd_fused: packed weight shapes do not match")
+    dev = dout.device
+    da2 = torch.empty((rows, d), dtype=torch.bfloat16, device=dev)
+    dh = torch.empty((rows, d), dtype=torch.bfloat16, device=dev)
+    da1 = torch.empty((rows, hidden), dtype=torch.bfloat16, device=dev)
+    act = torch.empty((rows, hidden), dtype=torch.bfloat16, device=dev)
+    nws = int(N.lib().cm_ffn_bwd_workspace_floats(rows, hidden))
+    ws = torch.empty((nws + hidden + d,), dtype=torch.float32, device=dev)
+    db1, db2 = ws[nws:nws + hidden], ws[nws + hidden:]
+    a = N.FfnBwdArgs()
+    a.rows, a.dim, a.hidden = rows, d, hidden
+    a.dout, a.w2t, a.w1t, a.pre = _ptr(dout), _ptr(w2t.data), _ptr(w1t.data), _ptr(pre)
+    a.da2, a.da1, a.act, a.dh, a.db1, a.db2 = _ptr(da2), _ptr(da1), _ptr(act), _ptr(dh), _ptr(db1), _ptr(db2)
+    a.alpha, a.p1, a.p2, a.seed1, a.seed2 = float(alpha), float(p1), float(p2), int(seed1), int(seed2)
+    a.workspace, a.workspace_floats, a.stream = _ptr(ws), nws, _stream()
+    _launch("cm_ffn_bwd_fused", N.lib().cm_ffn_bwd_fused, a, units=rows)
+    return da2, da1, act, dh, db1, db2
+
+
 def invalidate_caches(module: torch.nn.Module) -> None:
     """Drop every cached low-precision weight copy under ``module`` (cast_cached's per-parameter copies and the fused
     path's per-layer images).  The caches key on (parameter version, storage pointer): in-place writes made under
@@ -138,6 +182,8 @@ def invalidate_caches(module: torch.nn.Module) -> None:
     for p in module.parameters():
         if hasattr(p, "_cm_pack"):
             del p._cm_pack
+        if hasattr(p, "_cm_pack_t"):
+            del p._cm_pack_t
         if hasattr(p, "_cm_cast"):
             try:
                 del p._cm_cast

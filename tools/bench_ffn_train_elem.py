@@ -41,3 +41,13 @@ if __name__ == "__main__":
     print(f"cm_ffn_fused training forward, {rows} rows: {t:6.1f} us")
     t = timeit(lambda: ops.ffn_fused(x, ln, p1, b1, p2, b2, alpha=0.5, x_out=out, want_h=False))
     print(f"cm_ffn_fused inference forward, {rows} rows: {t:6.1f} us")
+    w2t, w1t = ops.PackedWeight(w2.t().contiguous()), ops.PackedWeight(w1.t().contiguous())
+    t = timeit(lambda: ops.ffn_bwd_fused(dout, w2t, w1t, pre, 0.5, 0.1, 0.1, 5, 6))
+    print(f"cm_ffn_bwd_fused (dout -> da2, da1, act, dh, db1, db2), {rows} rows: {t:6.1f} us")
+
+    def chain():
+        a2, b2_ = ops.bias_act_dropout_bwd(dout, None, 0.1, act=0, alpha=0.5, out_dtype=dt, seed=6)
+        g_ = torch.mm(a2, w2)
+        a1, b1_, ac = ops.bias_act_dropout_bwd(g_, None, 0.1, a=pre, act=1, seed=5, want_act=True)
+        return torch.mm(a1, w1)
+    print(f"  the same chain as separate launches: {timeit(chain):6.1f} us")
