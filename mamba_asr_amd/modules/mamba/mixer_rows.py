@@ -69,7 +69,13 @@ class _Derived:
 
     @staticmethod
     def make_key(m, cdt):
-        return (cdt,) + tuple((p._version, p.data_ptr()) for p in m.parameters())
+        # the module's parameter OBJECTS, listed once (Module.parameters() walks the module tree: 3 ms of host time per training step,
+        # which is host-bound); ops.invalidate_caches drops the list
+        pl = m.__dict__.get("_cm_plist")
+        if pl is None:
+            pl = list(m.parameters())
+            m.__dict__["_cm_plist"] = pl
+        return (cdt,) + tuple((p._version, p.data_ptr()) for p in pl)
 
 
 def _derived(m, sfx, cdt, scale) -> _Derived:

@@ -184,6 +184,9 @@ def invalidate_caches(module: torch.nn.Module) -> None:
             del p._cm_pack
         if hasattr(p, "_cm_pack_t"):
             del p._cm_pack_t
+    for m in module.modules():
+        if hasattr(m, "_cm_plist"):
+            del m._cm_plist
         if hasattr(p, "_cm_cast"):
             try:
                 del p._cm_cast
@@ -218,7 +221,14 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t.detach().to(torch.float32).contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # the raw handle of the current stream: torch.cuda.current_stream() builds a Stream object per call (2.5 us x 220 launches per
+    # forward; the training step is host-bound: 44.7 ms to enqueue 47 ms of kernels)
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
