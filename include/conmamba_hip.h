@@ -852,7 +852,7 @@ typedef struct cm_ffn_bwd_args {
     void *da2;                          /* (rows, 256) bf16 out                                                             */
     void *da1, *act;                    /* (rows, hidden) bf16 out                                                          */
     void *dh;                           /* (rows, 256) bf16 out                                                             */
-    float *db1, *db2;                   /* (hidden), (256) fp32 out (written)                                               */
+    float *db1, *db2;                   /* (hidden), (256) fp32 out (written); db2 = db1 + hidden: ONE (hidden + 256) buffer     */
     float alpha, p1, p2;
     float reserved1;
     uint64_t seed1, seed2;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
         float s = 0.f;
 #pragma unroll 8
         for (int r = 0; r < TOK; ++r) s += __uint_as_float((uint32_t)xn[r * XS + tid] << 16);
-        p.db2_part[(int64_t)blockIdx.x * D + tid] = s;
+        p.db2_part[(int64_t)blockIdx.x * (F + D) + tid] = s;      // a workgroup's partial row: [db1 (hidden) | db2 (256)]
     }
 
     f32x4 acc2[4][4];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
             float s = 0.f;                                           // fixed order over the 8 row groups
 #pragma unroll
             for (int g8 = 0; g8 < 8; ++g8) s += red[g8 * CH + tid];
-            p.db1_part[(int64_t)blockIdx.x * F + c * CH + tid] = s;
+            p.db1_part[(int64_t)blockIdx.x * (F + D) + c * CH + tid] = s;
         }
         read_frags(hfrag, 0, bfa);
 #pragma unroll
@@ -279,8 +279,9 @@ extern "C" int cm_ffn_bwd_fused(const cm_ffn_bwd_args *args) {
                CM_EALIGN, "ffn_bwd_fused: tensors must be 16-byte aligned");
     const int nwg = (a.rows + TOK - 1) / TOK;
     CM_REQUIRE(a.workspace_floats >= cm_ffn_bwd_workspace_floats(a.rows, a.hidden), CM_EINVAL, "ffn_bwd_fused: workspace smaller than cm_ffn_bwd_workspace_floats()");
-    a.db1_part = a.workspace;
-    a.db2_part = a.workspace + (int64_t)nwg * a.hidden;
+    CM_REQUIRE(a.db2 == a.db1 + a.hidden, CM_EINVAL, "ffn_bwd_fused: db2 must follow db1 (one (hidden + 256) fp32 buffer: one fold launch for both)");
+    a.db1_part = a.workspace;                                        // rows of (hidden + 256): [db1 | db2] per workgroup
+    a.db2_part = a.workspace + a.hidden;
     const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)8 * CH * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -294,7 +295,6 @@ extern "C" int cm_ffn_bwd_fused(const cm_ffn_bwd_args *args) {
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(nwg), dim3(NT), smem, st, a);
     if (int rc = cm_launch_status("cm_ffn_bwd_fused")) return rc;
-    hipLaunchKernelGGL(ffn_bwd_colsum_kernel, dim3((a.hidden + 31) / 32), dim3(256), 0, st, a.db1_part, nwg, a.hidden, a.db1);
-    hipLaunchKernelGGL(ffn_bwd_colsum_kernel, dim3((D + 31) / 32), dim3(256), 0, st, a.db2_part, nwg, D, a.db2);
+    hipLaunchKernelGGL(ffn_bwd_colsum_kernel, dim3((a.hidden + D + 31) / 32), dim3(256), 0, st, a.workspace, nwg, a.hidden + D, a.db1);
     return cm_launch_status("cm_ffn_bwd_fused(bias sums)");
 }
