@@ -66,6 +66,9 @@ class _Derived:
             self.A.append((-torch.exp(getattr(m, "A_b_log" if s else "A_log").detach().float())).contiguous())
         if cdt == torch.bfloat16 and len(sfx) == 2 and E % 32 == 0 and E <= 2048:
             self.xr_packed = [ops.PackedWeight(x) for x in self.xr]
+        # both directions' x_proj as ONE block-diagonal (2 RW, 2 E) matrix: the backward's input gradient (du += dx_dbl W_x) and weight
+        # gradient are one GEMM / one batched GEMM for the pair instead of one per direction (the step is host-bound: launches count)
+        self.xr_bd = torch.block_diag(*self.xr) if len(sfx) == 2 else None
 
     @staticmethod
     def make_key(m, cdt):
@@ -188,9 +191,14 @@ class MixerRowsFn(torch.autograd.Function):
         grads = []
         du2, dx2 = ducat.view(B * T, ndir * E), dxdbl.view(B * T, ndir * RW)
         dxr = []
-        for i in range(ndir):
-            dxr.append(ops.sum_leading(torch.bmm(dxdbl[:, :, RW * i:RW * (i + 1)].transpose(1, 2), ucat[:, :, E * i:E * (i + 1)])))   # (RW, E)
-            du2[:, E * i:E * (i + 1)].addmm_(dx2[:, RW * i:RW * (i + 1)], dv.xr[i])
+        if ndir == 2 and dv.xr_bd is not None:
+            full = ops.sum_leading(torch.bmm(dxdbl.transpose(1, 2), ucat))                # (2 RW, 2 E): the diagonal blocks are the two directions'
+            dxr = [full[:RW, :E], full[RW:, E:]]
+            du2.addmm_(dx2, dv.xr_bd)
+        else:
+            for i in range(ndir):
+                dxr.append(ops.sum_leading(torch.bmm(dxdbl[:, :, RW * i:RW * (i + 1)].transpose(1, 2), ucat[:, :, E * i:E * (i + 1)])))   # (RW, E)
+                du2[:, E * i:E * (i + 1)].addmm_(dx2[:, RW * i:RW * (i + 1)], dv.xr[i])
         convs = [getattr(m, "conv1d" + s) for s in sfx]
         cw = [c.weight.detach().float().reshape(E, -1) for c in convs]
         cb = [c.bias.detach().float() for c in convs]
