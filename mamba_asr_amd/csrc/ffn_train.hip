@@ -60,15 +60,16 @@ __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const cm_ffn_
     if (v >= p.rows * vpr) return;
     const int64_t e0 = v * 8;
     const int c = (int)(v % vpr) * 8;
-    float a[8], y[8];
+    float a[8], y[8], bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
+    if (p.bias) ld_vec<float>(p.bias + c, bs8);                      // two 16-byte loads (per-element loads: 8 extra vector-memory instructions per thread)
     const bool drop = p.p > 0.f;
     const float scale = drop ? cm_drop_scale(p.p) : 1.f;
     const uint32_t keep8 = drop ? cm_drop_keep8(p.seed, (uint64_t)v, cm_drop_thresh(p.p)) : 0xffu;
     uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float t = a[k] + (p.bias ? p.bias[c + k] : 0.f);
+        float t = a[k] + bs8[k];
         if (p.act == 1) t = sizeof(YT) == 2 ? cm_gelu_bf16(t) : cm_gelu(t);
         const bool keep = (keep8 >> k) & 1u;
         (k < 4 ? mlo : mhi) |= (keep ? 1u : 0u) << (8 * (k & 3));
@@ -186,12 +187,13 @@ __global__ __launch_bounds__(256) void bias_glu_fwd_kernel(const cm_ffn_elem_arg
     if (v >= p.rows * vpr) return;
     const int64_t r = v / vpr;
     const int c = (int)(v % vpr) * 8;
-    float a1[8], a2[8], y[8];
+    float a1[8], a2[8], y[8], b1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const AT *ar = reinterpret_cast<const AT *>(p.a) + r * 2 * p.dim;
     ld_vec<AT>(ar + c, a1);
     ld_vec<AT>(ar + p.dim + c, a2);
+    if (p.bias) ld_vec<float>(p.bias + c, b1), ld_vec<float>(p.bias + p.dim + c, b2);   // 16-byte loads (were 16 four-byte loads per thread)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) y[k] = (a1[k] + (p.bias ? p.bias[c + k] : 0.f)) * cm_sigmoid(a2[k] + (p.bias ? p.bias[p.dim + c + k] : 0.f));
+    for (int k = 0; k < 8; ++k) y[k] = (a1[k] + b1[k]) * cm_sigmoid(a2[k] + b2[k]);
     st_vec<AT>(reinterpret_cast<AT *>(p.y) + r * p.dim + c, y);
 }
 
@@ -299,8 +301,8 @@ extern "C" int cm_bias_act_dropout_fwd(const cm_ffn_elem_args *args) {
     CM_REQUIRE(args != nullptr, CM_EINVAL, "bias_act_dropout_fwd: args is NULL");
     const cm_ffn_elem_args &a = *args;
     if (int rc = check(a, "bias_act_dropout_fwd")) return rc;
-    CM_REQUIRE(a.a && a.y && cm_aligned(a.a, 16) && cm_aligned(a.y, 16) && (!a.res || cm_aligned(a.res, 16)), CM_EALIGN,
-               "bias_act_dropout_fwd: a / y (/ res) must be non-NULL and 16-byte aligned");
+    CM_REQUIRE(a.a && a.y && cm_aligned(a.a, 16) && cm_aligned(a.y, 16) && (!a.res || cm_aligned(a.res, 16)) && (!a.bias || cm_aligned(a.bias, 16)), CM_EALIGN,
+               "bias_act_dropout_fwd: a / y (/ res, bias) must be non-NULL and 16-byte aligned");
     const int64_t threads = a.rows * (a.dim / 8);
     const dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
