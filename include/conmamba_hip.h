@@ -834,9 +834,14 @@ typedef struct cm_ffn_args {
     float p1, p2;                       /* dropout probabilities behind the activation / behind the second Linear           */
     uint64_t seed1, seed2;
     float       *stats_out;             /* (2, rows) fp32 or NULL: mean, 1/std of LN(x)'s rows, as cm_layernorm_bwd reads them */
+    int32_t layout;                     /* 0: w1 / w2 / proj_w in cm_ffn_pack_weights' image (16-row x 32-column tiles, v_mfma_f32_16x16x32_bf16);
+                                           1: in cm_ffn_pack_weights32's (32 x 16 tiles, v_mfma_f32_32x32x16_bf16; inference forward only) */
+    int32_t reserved0;
 } cm_ffn_args;
 
 int cm_ffn_fused(const cm_ffn_args *args);
+/* row-major (rows, cols) bf16 -> the 32-row x 16-column fragment-tile image of cm_ffn_args.layout = 1 (rows % 32 == 0, cols % 16 == 0) */
+int cm_ffn_pack_weights32(const void *w, int32_t rows, int32_t cols, void *out, void *stream);
 
 /* The data-gradient chain of the same module's backward (what autograd does over modules/Conmamba.py:597-617 with two Dropout, two
  * addmm and one GELU backward), for the forward cm_ffn_fused's training variant ran (same dropout seeds):

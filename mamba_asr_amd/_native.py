@@ -256,7 +256,7 @@ class FfnArgs(C.Structure):
         ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
         ("proj_dim", i32), ("stream", vp), ("proj_w", vp), ("proj_b", fp), ("proj_out", vp),
         ("pre_out", vp), ("xn_out", vp), ("p1", C.c_float), ("p2", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
-        ("stats_out", fp),
+        ("stats_out", fp), ("layout", i32), ("reserved0", i32),
     ]
 
 
@@ -302,6 +302,7 @@ SYMBOLS = [
     ("cm_scan_cl_bwd_workspace_bytes", C.c_int64, [C.POINTER(ScanClBwdArgs)]),
     ("cm_scan_cl_bwd_auto_chunks", C.c_int, [C.c_int] * 4),
     ("cm_reflect_pad_tf", C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    ("cm_ffn_pack_weights32", C.c_int, [vp, i32, i32, vp, vp]),
     ("cm_ffn_bwd_workspace_floats", C.c_int64, [i32, i32]),
     ("cm_ffn_bwd_fused", C.c_int, [C.POINTER(FfnBwdArgs)]),
     ("cm_wgrad_supported", C.c_int, [i32, i32, i32]),

@@ -598,6 +598,8 @@ int launch(const cm_ffn_args &a) {
 
 }  // namespace
 
+int cm_ffn_fused32_launch(const cm_ffn_args &a);                  // ffn_fused32.hip
+
 extern "C" int cm_ffn_pack_weights(const void *w, int32_t rows, int32_t cols, void *out, void *stream) {
     CM_REQUIRE(w && out && rows > 0 && cols > 0, CM_EINVAL, "ffn_pack_weights: bad sizes or NULL tensor");
     CM_REQUIRE(rows % 16 == 0 && cols % 32 == 0, CM_EUNSUPPORTED, "ffn_pack_weights: needs rows %% 16 == 0 and cols %% 32 == 0");
@@ -629,6 +631,9 @@ extern "C" int cm_ffn_fused(const cm_ffn_args *args) {
                    (!a.n2_g || (cm_aligned(a.n2_g, 16) && cm_aligned(a.n2_b, 16))),
                CM_EALIGN, "ffn_fused: tensors must be 16-byte aligned");
     const bool train = a.pre_out || a.xn_out || a.stats_out || a.p1 > 0.f || a.p2 > 0.f;
+    CM_REQUIRE(a.layout == 0 || a.layout == 1, CM_EINVAL, "ffn_fused: layout must be 0 or 1");
+    CM_REQUIRE(a.layout == 0 || !train, CM_EUNSUPPORTED, "ffn_fused: the training forward takes layout 0 weights");
+    if (a.layout == 1) return cm_ffn_fused32_launch(a);
     if (train) {
         CM_REQUIRE(a.x_out && !a.addend && !a.n1_g && !a.n2_g && !a.proj_w && !a.h_out, CM_EINVAL,
                    "ffn_fused: the training forward writes x_out (+ pre_out, xn_out) only: no addend, n1, n2, projection or h_out");

@@ -37,7 +37,7 @@ class _LayerCache:
         self.ffn1, self.ffn2 = ffn(layer.ffn_module1), ffn(layer.ffn_module2)
         if ops.ffn_supported(self.ffn1["w1"].shape[1], self.ffn1["w1"].shape[0], dtype) and self.ffn1["w1"].is_cuda:
             for q in (self.ffn1, self.ffn2):                       # cm_ffn_fused's fragment-tiled weight images
-                q["w1p"], q["w2p"] = ops.PackedWeight(q["w1"]), ops.PackedWeight(q["w2"])
+                q["w1p"], q["w2p"] = ops.PackedWeight(q["w1"], ops.FFN_LAYOUT), ops.PackedWeight(q["w2"], ops.FFN_LAYOUT)
         self.norm1 = (f(layer.norm1.norm.weight), f(layer.norm1.norm.bias), layer.norm1.norm.eps)
         self.norm2 = (f(layer.norm2.norm.weight), f(layer.norm2.norm.bias), layer.norm2.norm.eps)
         m = layer.mamba
@@ -46,7 +46,7 @@ class _LayerCache:
         self.in_packed = None                                     # in_proj inside cm_ffn_fused (bf16, d_model 256, no bias)
         if (USE_FFN_INPROJ and dtype == torch.bfloat16 and self.in_proj.is_cuda and self.in_proj.shape[1] == 256
                 and self.in_proj.shape[0] % 256 == 0 and self.in_proj.shape[0] <= 4096 and m.in_proj.bias is None):
-            self.in_packed = ops.PackedWeight(self.in_proj)
+            self.in_packed = ops.PackedWeight(self.in_proj, ops.FFN_LAYOUT)   # streamed by cm_ffn_fused's projection epilogue only
         self.in_bias = None if m.in_proj.bias is None else c(m.in_proj.bias)
         half = 0.5 if m.if_devide_out else 1.0
         self.out_cat = c(torch.cat([m.out_proj.weight, m.out_proj.weight], dim=1) * half)      # (D, 2E)

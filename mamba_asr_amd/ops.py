@@ -1326,17 +1326,27 @@ def ffn_supported(d_model: int, hidden: int, dtype) -> bool:
     return dtype == torch.bfloat16 and d_model == 256 and hidden >= 256 and hidden % 256 == 0
 
 
-class PackedWeight:
-    """A bf16 (rows, cols) matrix in cm_ffn_fused's fragment-tiled layout (cm_ffn_pack_weights)."""
+# cm_ffn_fused's inference forward on v_mfma_f32_32x32x16_bf16 (csrc/ffn_fused32.hip, weights in the 32 x 16 tile image) instead of
+# 16x16x32 (csrc/ffn_fused.hip): CM_FFN_MFMA32=1
+FFN_LAYOUT = 32 if os.environ.get("CM_FFN_MFMA32", "0") == "1" else 16
 
-    def __init__(self, w: torch.Tensor):
+
+class PackedWeight:
+    """A bf16 (rows, cols) matrix in a fragment-tiled image: ``layout`` 16 = 16-row x 32-column tiles (cm_ffn_pack_weights: every
+    kernel that streams packed weights), 32 = 32 x 16 tiles (cm_ffn_pack_weights32: cm_ffn_fused with cm_ffn_args.layout = 1)."""
+
+    def __init__(self, w: torch.Tensor, layout: int = 16):
         _dev_check(w)
         if w.dtype != torch.bfloat16 or w.dim() != 2:
             raise RuntimeError("PackedWeight: expected a 2-D bf16 tensor")
+        if layout not in (16, 32):
+            raise RuntimeError("PackedWeight: layout must be 16 or 32")
         w = w.contiguous()
         self.shape = tuple(w.shape)
+        self.layout = layout
         self.data = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
-        rc = N.lib().cm_ffn_pack_weights(_ptr(w), w.shape[0], w.shape[1], _ptr(self.data), _stream())
+        fn = N.lib().cm_ffn_pack_weights if layout == 16 else N.lib().cm_ffn_pack_weights32
+        rc = fn(_ptr(w), w.shape[0], w.shape[1], _ptr(self.data), _stream())
         N.check(rc, "cm_ffn_pack_weights")
 
 
@@ -1358,10 +1368,15 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
         raise RuntimeError("ffn_fused: x must be a contiguous fp32 (rows, 256) tensor")
     if d != 256:
         raise RuntimeError(f"ffn_fused: d_model must be 256 (got {d})")
-    w1 = w1 if isinstance(w1, PackedWeight) else PackedWeight(w1)
-    w2 = w2 if isinstance(w2, PackedWeight) else PackedWeight(w2)
+    lay = w1.layout if isinstance(w1, PackedWeight) else (w2.layout if isinstance(w2, PackedWeight) else (16 if train is not None else FFN_LAYOUT))
+    w1 = w1 if isinstance(w1, PackedWeight) else PackedWeight(w1, lay)
+    w2 = w2 if isinstance(w2, PackedWeight) else PackedWeight(w2, lay)
     if w1.shape[1] != d or w2.shape != (d, w1.shape[0]):
         raise RuntimeError("ffn_fused: weight shapes do not match x")
+    if w1.layout != w2.layout or (proj_w is not None and isinstance(proj_w, PackedWeight) and proj_w.layout != w1.layout):
+        raise RuntimeError("ffn_fused: w1, w2 and proj_w must be packed in the same layout")
+    if train is not None and w1.layout != 16:
+        raise RuntimeError("ffn_fused: the training forward takes layout-16 weights")
     for t in (b1, b2) + tuple(pre_norm[:2]):
         if t.dtype != torch.float32:
             raise RuntimeError("ffn_fused: biases and LayerNorm parameters must be fp32")
@@ -1369,6 +1384,7 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
     a.rows, a.dim, a.hidden = rows, d, w1.shape[0]
     a.x, a.pre_g, a.pre_b, a.pre_eps = _ptr(x), _ptr(pre_norm[0]), _ptr(pre_norm[1]), float(pre_norm[2])
     a.w1, a.b1, a.w2, a.b2, a.alpha = _ptr(w1.data), _ptr(b1), _ptr(w2.data), _ptr(b2), float(alpha)
+    a.layout = 1 if w1.layout == 32 else 0
     if addend is not None:
         if addend.dtype != torch.bfloat16 or not addend.is_contiguous() or addend.shape != x.shape:
             raise RuntimeError("ffn_fused: addend must be a contiguous bf16 tensor shaped like x")
