@@ -662,6 +662,13 @@ typedef struct cm_layernorm_args {
     void  *stream;
     const float *dres;           /* backward, optional: (rows, dim) fp32 added to dx (the residual branch's gradient: the
                                     pre-norm block's dx = dres + LayerNorm'(dy) in one pass); fp32 x and dim <= 1024 only */
+    /* optional epilogue y = act(LN(x)) * chan_mask[row / mask_rows][col % mask_c] -- the front end's Conv2d block tail (LayerNorm over
+       (freq, channel) -> LeakyReLU -> Dropout2d, one keep / (1 - p) factor per (sample, channel)); the backward recomputes LN's
+       output for the activation's derivative and needs beta then */
+    int32_t act;                 /* 0 none, 1 LeakyReLU(act_slope)                                                          */
+    float   act_slope;
+    const float *chan_mask;      /* (rows / mask_rows, mask_c) fp32 or NULL; mask_c a multiple of 4 dividing dim            */
+    int32_t mask_rows, mask_c;
 } cm_layernorm_args;
 
 int64_t cm_layernorm_bwd_workspace_floats(int64_t rows, int32_t dim);

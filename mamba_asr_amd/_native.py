@@ -189,6 +189,7 @@ class LayerNormArgs(C.Structure):
         ("rows", i64), ("dim", i32), ("x_dtype", i32), ("y_dtype", i32), ("eps", C.c_float),
         ("x", vp), ("gamma", fp), ("beta", fp), ("y", vp), ("mean", fp), ("rstd", fp),
         ("dy", vp), ("dx", vp), ("dgamma", fp), ("dbeta", fp), ("workspace", fp), ("stream", vp), ("dres", fp),
+        ("act", i32), ("act_slope", C.c_float), ("chan_mask", fp), ("mask_rows", i32), ("mask_c", i32),
     ]
 
 

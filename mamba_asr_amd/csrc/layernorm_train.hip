@@ -34,6 +34,34 @@ __device__ __forceinline__ void st4(cm_bf16 *p, const float4 v) {
     *reinterpret_cast<uint2 *>(p) = w;
 }
 
+// Optional epilogue (the front end's Conv2d blocks: LayerNorm over (freq, channel) -> LeakyReLU -> Dropout2d, speechbrain
+// ConvolutionFrontEnd; reference hparams/CTC/conmamba_large.yaml:187-194): y = leaky(LN(x)) * chan_mask[row / mask_rows][col % mask_c].
+// As three torch kernels behind the LayerNorm the block's fp32 activations made four extra trips through HBM forward and backward.
+__device__ __forceinline__ float4 ln_epilogue(const cm_layernorm_args &p, float4 y, int64_t row, int c) {
+    if (p.act == 1) {
+        y.x = y.x > 0.f ? y.x : y.x * p.act_slope; y.y = y.y > 0.f ? y.y : y.y * p.act_slope;
+        y.z = y.z > 0.f ? y.z : y.z * p.act_slope; y.w = y.w > 0.f ? y.w : y.w * p.act_slope;
+    }
+    if (p.chan_mask) {
+        const float4 m = *reinterpret_cast<const float4 *>(p.chan_mask + (row / p.mask_rows) * p.mask_c + c % p.mask_c);
+        y.x *= m.x, y.y *= m.y, y.z *= m.z, y.w *= m.w;
+    }
+    return y;
+}
+// the gradient arriving at LN's output through that epilogue: d * mask * leaky'(z), z = xhat * gamma + beta recomputed
+__device__ __forceinline__ float4 ln_epilogue_grad(const cm_layernorm_args &p, float4 d, float4 xh, float4 g, int64_t row, int c) {
+    if (p.chan_mask) {
+        const float4 m = *reinterpret_cast<const float4 *>(p.chan_mask + (row / p.mask_rows) * p.mask_c + c % p.mask_c);
+        d.x *= m.x, d.y *= m.y, d.z *= m.z, d.w *= m.w;
+    }
+    if (p.act == 1) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.beta + c);
+        d.x *= fmaf(xh.x, g.x, b.x) > 0.f ? 1.f : p.act_slope; d.y *= fmaf(xh.y, g.y, b.y) > 0.f ? 1.f : p.act_slope;
+        d.z *= fmaf(xh.z, g.z, b.z) > 0.f ? 1.f : p.act_slope; d.w *= fmaf(xh.w, g.w, b.w) > 0.f ? 1.f : p.act_slope;
+    }
+    return d;
+}
+
 template <int LPR> __device__ __forceinline__ float row_sum(float v) {
     v = cm_group_sum<16>(v);
     if constexpr (LPR == 64) {
@@ -88,8 +116,8 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_fwd_kernel(const cm_layern
             for (int i = 0; i < MAXV; ++i) {
                 if (on[i])
                     st4(y + row * dim + 4 * (lr + LPR * i),
-                        make_float4(fmaf(v[i].x * rstd, g[i].x, b[i].x), fmaf(v[i].y * rstd, g[i].y, b[i].y),
-                                    fmaf(v[i].z * rstd, g[i].z, b[i].z), fmaf(v[i].w * rstd, g[i].w, b[i].w)));
+                        ln_epilogue(p, make_float4(fmaf(v[i].x * rstd, g[i].x, b[i].x), fmaf(v[i].y * rstd, g[i].y, b[i].y),
+                                                   fmaf(v[i].z * rstd, g[i].z, b[i].z), fmaf(v[i].w * rstd, g[i].w, b[i].w)), row, 4 * (lr + LPR * i)));
             }
             if (lr == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
         }
@@ -132,6 +160,7 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
                 d = ld4<YT>(dy + rc * dim + 4 * (lr + LPR * i));
                 if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);     // rows past the end add nothing to the column sums
                 xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+                if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g[i], rc, 4 * (lr + LPR * i));
             }
             gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
             s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
@@ -231,8 +260,8 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const cm_layernorm_arg
             if (on[i]) {
                 const int c = 4 * (t + 256 * i);
                 const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c), b = *reinterpret_cast<const float4 *>(p.beta + c);
-                st4(y + row * dim + c, make_float4(fmaf(v[i].x * rstd, g.x, b.x), fmaf(v[i].y * rstd, g.y, b.y),
-                                                   fmaf(v[i].z * rstd, g.z, b.z), fmaf(v[i].w * rstd, g.w, b.w)));
+                st4(y + row * dim + c, ln_epilogue(p, make_float4(fmaf(v[i].x * rstd, g.x, b.x), fmaf(v[i].y * rstd, g.y, b.y),
+                                                                  fmaf(v[i].z * rstd, g.z, b.z), fmaf(v[i].w * rstd, g.w, b.w)), row, c));
             }
         }
         if (t == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
@@ -264,9 +293,11 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const cm_layernorm_arg
             xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (on[i]) {
                 const int c = 4 * (t + 256 * i);
-                const float4 v = ld4<XT>(x + row * dim + c), d = ld4<YT>(dy + row * dim + c);
+                const float4 v = ld4<XT>(x + row * dim + c);
+                float4 d = ld4<YT>(dy + row * dim + c);
                 const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c);
                 xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+                if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g, row, c);
                 gy[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
                 dg[i].x = fmaf(d.x, xh[i].x, dg[i].x); dg[i].y = fmaf(d.y, xh[i].y, dg[i].y);
                 dg[i].z = fmaf(d.z, xh[i].z, dg[i].z); dg[i].w = fmaf(d.w, xh[i].w, dg[i].w);

@@ -1095,7 +1095,21 @@ def _layernorm_args(x2, weight, eps, y_dtype):
     return a
 
 
-def layernorm_fwd(x, weight, bias, eps, out_dtype=None):
+def _ln_epilogue(a, x2, leaky_slope, chan_mask, mask_rows):
+    """Fill the optional activation + channel-mask epilogue of cm_layernorm_args."""
+    if leaky_slope is not None:
+        a.act, a.act_slope = 1, float(leaky_slope)
+    if chan_mask is not None:
+        _dev_check(chan_mask)
+        if chan_mask.dtype != torch.float32 or not chan_mask.is_contiguous() or chan_mask.dim() != 2:
+            raise RuntimeError("layernorm: chan_mask must be a contiguous fp32 (groups, channels) tensor")
+        c = chan_mask.shape[1]
+        if c % 4 or x2.shape[1] % c or x2.shape[0] != chan_mask.shape[0] * mask_rows:
+            raise RuntimeError("layernorm: chan_mask (groups, channels) needs channels % 4 == 0, dim % channels == 0, rows == groups * mask_rows")
+        a.chan_mask, a.mask_rows, a.mask_c = _ptr(chan_mask), int(mask_rows), c
+
+
+def layernorm_fwd(x, weight, bias, eps, out_dtype=None, leaky_slope=None, chan_mask=None, mask_rows=1):
     """LayerNorm over the last axis (cm_layernorm_fwd) -> (y, mean, rstd); x fp32 or bf16, contiguous rows; y in
     `out_dtype` (default fp32: what torch's autocast gives, reference modules/Conmamba.py:597-620)."""
     _dev_check(x, weight, bias)
@@ -1110,11 +1124,12 @@ def layernorm_fwd(x, weight, bias, eps, out_dtype=None):
     stats = torch.empty((2, x2.shape[0]), dtype=torch.float32, device=x.device)
     a = _layernorm_args(x2, w, eps, out_dtype)
     a.beta, a.y, a.mean, a.rstd = _ptr(b), _ptr(y), _ptr(stats[0]), _ptr(stats[1])
+    _ln_epilogue(a, x2, leaky_slope, chan_mask, mask_rows)
     _launch("cm_layernorm_fwd", N.lib().cm_layernorm_fwd, a, units=x2.shape[0])
     return y.view(x.shape), x2, stats
 
 
-def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True, dres=None):
+def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True, dres=None, bias=None, leaky_slope=None, chan_mask=None, mask_rows=1):
     """-> (dx (x2's dtype and shape) or None, dgamma, dbeta (dim) fp32) of layernorm_fwd (cm_layernorm_bwd, deterministic).
     ``dres`` (fp32, x2's shape; fp32 x2, dim <= 1024): added to dx in the same pass (the residual branch's gradient)."""
     _dev_check(dy, x2, stats, weight)
@@ -1128,6 +1143,10 @@ def layernorm_bwd(dy, x2, stats, weight, eps, need_dx=True, dres=None):
     a = _layernorm_args(x2, w, eps, dy2.dtype)
     a.mean, a.rstd, a.dy, a.dx = _ptr(stats[0]), _ptr(stats[1]), _ptr(dy2), _ptr(dx)
     a.dgamma, a.dbeta, a.workspace = _ptr(dgb[0]), _ptr(dgb[1]), _ptr(ws)
+    if leaky_slope is not None or chan_mask is not None:
+        bb = bias.detach().float().contiguous()                   # the activation's derivative needs LN's output: beta
+        a.beta = _ptr(bb)
+        _ln_epilogue(a, x2, leaky_slope, chan_mask, mask_rows)
     fused_res = dres is not None and need_dx and x2.dtype == torch.float32 and x2.shape[1] <= 1024
     if fused_res:
         _dev_check(dres)
@@ -1161,6 +1180,34 @@ class LayerNormFn(torch.autograd.Function):
             dy = dy.float()
         dx, dg, db = layernorm_bwd(dy, x2, stats, weight, ctx.eps, need_dx=ctx.needs_input_grad[0])
         return (dx.view(ctx.shape) if dx is not None else None), dg.to(weight.dtype), db.to(weight.dtype), None, None
+
+
+class LnActDropFn(torch.autograd.Function):
+    """y = LeakyReLU(LayerNorm(x)) * chan_mask -- the tail of a front-end Conv2d block (LayerNorm over (freq, channel) -> LeakyReLU ->
+    Dropout2d with one factor per (sample, channel)) as ONE kernel forward and ONE backward (cm_layernorm_fwd / _bwd with the
+    epilogue fields).  x (batch, time, freq, channel) contiguous; weight / bias (freq * channel); chan_mask (batch, channel) fp32 with
+    the 1 / keep scale folded in, or None.  ``out_dtype``: what the consumer (the next Conv2d / Linear under autocast) rounds to anyway:
+    the fp32 result is rounded once, here."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, slope, chan_mask, out_dtype):
+        b, t, f, c = x.shape
+        x2 = x.reshape(b * t, f * c)
+        y, x2s, stats = layernorm_fwd(x2, weight, bias, eps, out_dtype, leaky_slope=slope, chan_mask=chan_mask, mask_rows=t)
+        ctx.save_for_backward(x2s, stats, weight, bias, chan_mask if chan_mask is not None else weight.new_empty(0))
+        ctx.cfg = (eps, slope, t, chan_mask is not None, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats, weight, bias, mask = ctx.saved_tensors
+        eps, slope, t, has_mask, shape = ctx.cfg
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dg, db = layernorm_bwd(dy.view(x2.shape[0], -1), x2, stats, weight, eps, need_dx=ctx.needs_input_grad[0], bias=bias, leaky_slope=slope,
+                                   chan_mask=mask if has_mask else None, mask_rows=t)
+        return (dx.view(shape) if dx is not None else None), dg.to(weight.dtype), db.to(weight.dtype), None, None, None, None
 
 
 def ln_pw_glu(x, y, alpha, norm, w, bias, x_out=None):

@@ -30,6 +30,10 @@ class Swish(nn.Module):
 USE_NATIVE_LN = os.environ.get("CM_NATIVE_LN", "1") == "1"
 
 
+# the front-end Conv2d block's LayerNorm -> LeakyReLU -> Dropout2d as one kernel each way (ops.LnActDropFn); CM_CNN_TAIL=0 = three
+FUSED_CNN_TAIL = os.environ.get("CM_CNN_TAIL", "1") == "1"
+
+
 # CM_LN_LOW_OUT=0: LayerNorms in front of a projection return fp32 under autocast (torch's behaviour) instead of the
 # projection's operand dtype
 LN_LOW_OUT = os.environ.get("CM_LN_LOW_OUT", "1") == "1"
@@ -454,6 +458,18 @@ class _ConvLayer(nn.Module):
         else:
             y = F.pad(x.unsqueeze(0), (0, 0, p, p, p, p), mode="reflect").squeeze(0).permute(0, 3, 1, 2)
         y = self.conv(y).permute(0, 2, 3, 1)                       # (b, t', f', c) view, contiguous for channels_last
+        ln = self.norm.norm
+        dim = y.shape[2] * y.shape[3]
+        if (USE_NATIVE_LN and FUSED_CNN_TAIL and y.is_cuda and y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16) and dim % 4 == 0
+                and dim <= 4096 and y.shape[3] % 4 == 0 and ln.weight is not None and ln.bias is not None and tuple(ln.normalized_shape) == tuple(y.shape[2:])):
+            # LayerNorm -> LeakyReLU -> Dropout2d as one kernel each way; the result is rounded ONCE to what the consumer (the next
+            # block's Conv2d / the Linear behind the front end) would round it to under autocast
+            mask = None
+            if self.training and self.drop.p > 0:
+                keep = 1.0 - self.drop.p
+                mask = torch.empty((y.shape[0], y.shape[3]), dtype=torch.float32, device=y.device).bernoulli_(keep).div_(keep)
+            out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else y.dtype
+            return ops.LnActDropFn.apply(y, ln.weight.reshape(dim), ln.bias.reshape(dim), ln.eps, self.act.negative_slope, mask, out_dtype)
         y = self.act(self.norm(y))
         if self.training and self.drop.p > 0:
             # Dropout2d = one Bernoulli draw per (sample, channel), scaled by 1/keep.  Applied as a broadcast product on

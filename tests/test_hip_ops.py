@@ -694,3 +694,41 @@ def test_wgrad_falls_back_to_batched_gemms_for_other_shapes():
     got = ops.wgrad(a, b, nbatch=6)
     ref = a.double().t() @ b.double()
     assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-2      # per-chunk products are rounded to bf16
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 40, 64), (3, 17, 20, 32), (2, 9, 8, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop", [False, True])
+def test_layernorm_leaky_dropout2d_epilogue(shape, dtype, drop):
+    """ops.LnActDropFn (cm_layernorm_fwd / _bwd with the activation + channel-mask epilogue: the front-end Conv2d block's
+    LayerNorm over (freq, channel) -> LeakyReLU(0.01) -> Dropout2d) against the same three steps in torch, fp64, forward and all
+    gradients; wide rows (40 x 64 = 2560) and the 64-lane / 16-lane row kernels."""
+    from mamba_asr_amd import ops
+    b, t, f, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(b, t, f, c, generator=g)
+    w, bias = 1 + 0.2 * torch.randn(f * c, generator=g), 0.2 * torch.randn(f * c, generator=g)
+    mask = (torch.rand(b, c, generator=g) > 0.3).float() / 0.7 if drop else None
+    dy = torch.randn(b, t, f, c, generator=g)
+    # the reference sees the values the kernel sees (bf16-rounded x, dy): a LayerNorm output next to 0 would otherwise change the
+    # LeakyReLU branch between the two
+    x, dy = x.to(dtype).float(), dy.to(dtype).float()
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.layer_norm(xr.view(b, t, f * c), (f * c,), wr, br, 1e-5), 0.01).view(b, t, f, c)
+    if drop:
+        ref = ref * mask.double()[:, None, None, :]
+    gref = torch.autograd.grad(ref, [xr, wr, br], dy.double())
+    xg = x.to(dtype).to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    got = ops.LnActDropFn.apply(xg, wg, bg, 1e-5, 0.01, mask.to(DEV) if drop else None, dtype)
+    ggot = torch.autograd.grad(got, [xg, wg, bg], dy.to(dtype).to(DEV))
+    if dtype == torch.float32:
+        tol = dict(rtol=1e-4, atol=1e-4)
+        ref_in = ref
+    else:
+        tol = dict(rtol=3e-2, atol=3e-2)                          # the bf16 rounding of the outputs
+        ref_in = ref
+    torch.testing.assert_close(got.double().cpu(), ref_in.detach(), **tol)
+    for a_, r_ in zip(ggot, gref):
+        scale = max(1.0, float(r_.abs().max()))
+        torch.testing.assert_close(a_.double().cpu(), r_, rtol=tol["rtol"], atol=tol["atol"] * scale)
