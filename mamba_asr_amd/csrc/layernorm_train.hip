@@ -37,21 +37,23 @@ __device__ __forceinline__ void st4(cm_bf16 *p, const float4 v) {
 // Optional epilogue (the front end's Conv2d blocks: LayerNorm over (freq, channel) -> LeakyReLU -> Dropout2d, speechbrain
 // ConvolutionFrontEnd; reference hparams/CTC/conmamba_large.yaml:187-194): y = leaky(LN(x)) * chan_mask[row / mask_rows][col % mask_c].
 // As three torch kernels behind the LayerNorm the block's fp32 activations made four extra trips through HBM forward and backward.
-__device__ __forceinline__ float4 ln_epilogue(const cm_layernorm_args &p, float4 y, int64_t row, int c) {
+// mrow: the mask row of this LayerNorm row (chan_mask + (row / mask_rows) * mask_c, computed ONCE per row: a 64-bit division per
+// 16-byte group made the wide forward 1.8x slower than without the epilogue), mc: the group's channel offset c % mask_c (fixed per thread)
+__device__ __forceinline__ float4 ln_epilogue(const cm_layernorm_args &p, float4 y, const float *mrow, int mc) {
     if (p.act == 1) {
         y.x = y.x > 0.f ? y.x : y.x * p.act_slope; y.y = y.y > 0.f ? y.y : y.y * p.act_slope;
         y.z = y.z > 0.f ? y.z : y.z * p.act_slope; y.w = y.w > 0.f ? y.w : y.w * p.act_slope;
     }
-    if (p.chan_mask) {
-        const float4 m = *reinterpret_cast<const float4 *>(p.chan_mask + (row / p.mask_rows) * p.mask_c + c % p.mask_c);
+    if (mrow) {
+        const float4 m = *reinterpret_cast<const float4 *>(mrow + mc);
         y.x *= m.x, y.y *= m.y, y.z *= m.z, y.w *= m.w;
     }
     return y;
 }
 // the gradient arriving at LN's output through that epilogue: d * mask * leaky'(z), z = xhat * gamma + beta recomputed
-__device__ __forceinline__ float4 ln_epilogue_grad(const cm_layernorm_args &p, float4 d, float4 xh, float4 g, int64_t row, int c) {
-    if (p.chan_mask) {
-        const float4 m = *reinterpret_cast<const float4 *>(p.chan_mask + (row / p.mask_rows) * p.mask_c + c % p.mask_c);
+__device__ __forceinline__ float4 ln_epilogue_grad(const cm_layernorm_args &p, float4 d, float4 xh, float4 g, const float *mrow, int mc, int c) {
+    if (mrow) {
+        const float4 m = *reinterpret_cast<const float4 *>(mrow + mc);
         d.x *= m.x, d.y *= m.y, d.z *= m.z, d.w *= m.w;
     }
     if (p.act == 1) {
@@ -60,6 +62,9 @@ __device__ __forceinline__ float4 ln_epilogue_grad(const cm_layernorm_args &p, f
         d.z *= fmaf(xh.z, g.z, b.z) > 0.f ? 1.f : p.act_slope; d.w *= fmaf(xh.w, g.w, b.w) > 0.f ? 1.f : p.act_slope;
     }
     return d;
+}
+__device__ __forceinline__ const float *ln_mask_row(const cm_layernorm_args &p, int64_t row) {
+    return p.chan_mask ? p.chan_mask + (int64_t)((uint32_t)row / (uint32_t)p.mask_rows) * p.mask_c : nullptr;
 }
 
 template <int LPR> __device__ __forceinline__ float row_sum(float v) {
@@ -82,10 +87,12 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_fwd_kernel(const cm_layern
     const XT *x = reinterpret_cast<const XT *>(p.x);
     YT *y = reinterpret_cast<YT *>(p.y);
     bool on[MAXV];
+    int mcol[MAXV];
     float4 g[MAXV], b[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = 4 * (lr + LPR * i);
+        mcol[i] = p.chan_mask ? c % p.mask_c : 0;
         on[i] = c < dim;
         g[i] = on[i] ? *reinterpret_cast<const float4 *>(p.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         b[i] = on[i] ? *reinterpret_cast<const float4 *>(p.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -112,12 +119,13 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_fwd_kernel(const cm_layern
         }
         const float rstd = rsqrtf(row_sum<LPR>(q) * inv + p.eps);
         if (ok) {
+            const float *mrow = ln_mask_row(p, row);
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 if (on[i])
                     st4(y + row * dim + 4 * (lr + LPR * i),
                         ln_epilogue(p, make_float4(fmaf(v[i].x * rstd, g[i].x, b[i].x), fmaf(v[i].y * rstd, g[i].y, b[i].y),
-                                                   fmaf(v[i].z * rstd, g[i].z, b[i].z), fmaf(v[i].w * rstd, g[i].w, b[i].w)), row, 4 * (lr + LPR * i)));
+                                                   fmaf(v[i].z * rstd, g[i].z, b[i].z), fmaf(v[i].w * rstd, g[i].w, b[i].w)), mrow, mcol[i]));
             }
             if (lr == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
         }
@@ -136,10 +144,12 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
     const YT *dy = reinterpret_cast<const YT *>(p.dy);
     XT *dx = reinterpret_cast<XT *>(p.dx);
     bool on[MAXV];
+    int mcol[MAXV];
     float4 g[MAXV], dg[MAXV], db[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = 4 * (lr + LPR * i);
+        mcol[i] = p.chan_mask ? c % p.mask_c : 0;
         on[i] = c < dim;
         g[i] = on[i] ? *reinterpret_cast<const float4 *>(p.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
         const bool ok = row < p.rows;
         const int64_t rc = ok ? row : p.rows - 1;
         const float mean = p.mean[rc], rstd = p.rstd[rc];
+        const float *mrow = ln_mask_row(p, rc);
         float4 xh[MAXV], gy[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
                 d = ld4<YT>(dy + rc * dim + 4 * (lr + LPR * i));
                 if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);     // rows past the end add nothing to the column sums
                 xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-                if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g[i], rc, 4 * (lr + LPR * i));
+                if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g[i], mrow, mcol[i], 4 * (lr + LPR * i));
             }
             gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
             s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
@@ -222,7 +233,7 @@ __device__ __forceinline__ float block_sum(float v, float (*sh)[4], int &phase) 
     float *slot = sh[phase & 1];
     phase ^= 1;
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
-    __syncthreads();
+    cm_lds_barrier();                                              // LDS only: __syncthreads() would also drain the next row's loads (vmcnt)
     return (slot[0] + slot[1]) + (slot[2] + slot[3]);
 }
 
@@ -235,16 +246,34 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const cm_layernorm_arg
     const XT *x = reinterpret_cast<const XT *>(p.x);
     YT *y = reinterpret_cast<YT *>(p.y);
     bool on[MAXV];
+    int mcol[MAXV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) on[i] = 4 * (t + 256 * i) < dim;
+    for (int i = 0; i < MAXV; ++i) on[i] = 4 * (t + 256 * i) < dim, mcol[i] = p.chan_mask ? (4 * (t + 256 * i)) % p.mask_c : 0;
+    // gamma / beta live in registers for all rows, and a row's mask values are loaded BEFORE the next row is requested: the
+    // memory counter is in order, so a parameter load issued behind the prefetch made its wait drain the prefetch
+    float4 gw[MAXV], bw[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        gw[i] = on[i] ? *reinterpret_cast<const float4 *>(p.gamma + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bw[i] = on[i] ? *reinterpret_cast<const float4 *>(p.beta + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 nv[MAXV];
+    auto request = [&](int64_t row) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) nv[i] = on[i] ? ld4<XT>(x + row * dim + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if ((int64_t)blockIdx.x < p.rows) request(blockIdx.x);
     for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
-        float4 v[MAXV];
+        float4 v[MAXV], mk[MAXV];
         float s = 0.f;
+        const float *mrow = ln_mask_row(p, row);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            v[i] = on[i] ? ld4<XT>(x + row * dim + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = nv[i];
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            mk[i] = (mrow && on[i]) ? *reinterpret_cast<const float4 *>(mrow + mcol[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
+        if (row + gridDim.x < p.rows) request(row + gridDim.x);   // the next row travels under this row's two reductions
         const float mean = block_sum(s, sh, phase) * inv;
         float q = 0.f;
 #pragma unroll
@@ -259,9 +288,10 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const cm_layernorm_arg
         for (int i = 0; i < MAXV; ++i) {
             if (on[i]) {
                 const int c = 4 * (t + 256 * i);
-                const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c), b = *reinterpret_cast<const float4 *>(p.beta + c);
-                st4(y + row * dim + c, ln_epilogue(p, make_float4(fmaf(v[i].x * rstd, g.x, b.x), fmaf(v[i].y * rstd, g.y, b.y),
-                                                                  fmaf(v[i].z * rstd, g.z, b.z), fmaf(v[i].w * rstd, g.w, b.w)), row, c));
+                const float4 g = gw[i], b = bw[i];
+                float4 o = make_float4(fmaf(v[i].x * rstd, g.x, b.x), fmaf(v[i].y * rstd, g.y, b.y), fmaf(v[i].z * rstd, g.z, b.z), fmaf(v[i].w * rstd, g.w, b.w));
+                o = ln_epilogue(p, o, nullptr, 0);                // activation
+                st4(y + row * dim + c, make_float4(o.x * mk[i].x, o.y * mk[i].y, o.z * mk[i].z, o.w * mk[i].w));
             }
         }
         if (t == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
@@ -278,14 +308,46 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const cm_layernorm_arg
     const YT *dy = reinterpret_cast<const YT *>(p.dy);
     XT *dx = reinterpret_cast<XT *>(p.dx);
     bool on[MAXV];
+    int mcol[MAXV];
     float4 dg[MAXV], db[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         on[i] = 4 * (t + 256 * i) < dim;
+        mcol[i] = p.chan_mask ? (4 * (t + 256 * i)) % p.mask_c : 0;
         dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // the NEXT row's x / dy are requested before this row's reductions: with 512 workgroups (two per CU) walking 125 rows each, a row's
+    // load -> sum -> barrier -> sum -> barrier -> store chain ran at 1.8 TB/s
+    float4 gw[MAXV], bw[MAXV];                                     // gamma (and beta for the activation) in registers for all rows
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        gw[i] = on[i] ? *reinterpret_cast<const float4 *>(p.gamma + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bw[i] = (on[i] && p.act == 1) ? *reinterpret_cast<const float4 *>(p.beta + 4 * (t + 256 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 nx[MAXV], nd[MAXV];
+    float nmean = 0.f, nrstd = 0.f;
+    auto request = [&](int64_t row) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (on[i]) {
+                const int c = 4 * (t + 256 * i);
+                nx[i] = ld4<XT>(x + row * dim + c);
+                nd[i] = ld4<YT>(dy + row * dim + c);
+            }
+        }
+        nmean = p.mean[row], nrstd = p.rstd[row];
+    };
+    if ((int64_t)blockIdx.x < p.rows) request(blockIdx.x);
     for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
-        const float mean = p.mean[row], rstd = p.rstd[row];
+        const float mean = nmean, rstd = nrstd;
+        float4 cx[MAXV], cd[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) cx[i] = nx[i], cd[i] = nd[i];
+        const float *mrow = ln_mask_row(p, row);
+        float4 mk[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) mk[i] = (mrow && on[i]) ? *reinterpret_cast<const float4 *>(mrow + mcol[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (row + gridDim.x < p.rows) request(row + gridDim.x);  // behind the mask loads: the memory counter is in order
         float4 xh[MAXV], gy[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -293,11 +355,17 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const cm_layernorm_arg
             xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (on[i]) {
                 const int c = 4 * (t + 256 * i);
-                const float4 v = ld4<XT>(x + row * dim + c);
-                float4 d = ld4<YT>(dy + row * dim + c);
-                const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c);
+                const float4 v = cx[i];
+                float4 d = cd[i];
+                const float4 g = gw[i];
                 xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-                if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g, row, c);
+                d.x *= mk[i].x, d.y *= mk[i].y, d.z *= mk[i].z, d.w *= mk[i].w;
+                if (p.act == 1) {
+                    const float4 b = bw[i];
+                    d.x *= fmaf(xh[i].x, g.x, b.x) > 0.f ? 1.f : p.act_slope; d.y *= fmaf(xh[i].y, g.y, b.y) > 0.f ? 1.f : p.act_slope;
+                    d.z *= fmaf(xh[i].z, g.z, b.z) > 0.f ? 1.f : p.act_slope; d.w *= fmaf(xh[i].w, g.w, b.w) > 0.f ? 1.f : p.act_slope;
+                }
+                (void)c;
                 gy[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
                 dg[i].x = fmaf(d.x, xh[i].x, dg[i].x); dg[i].y = fmaf(d.y, xh[i].y, dg[i].y);
                 dg[i].z = fmaf(d.z, xh[i].z, dg[i].z); dg[i].w = fmaf(d.w, xh[i].w, dg[i].w);
@@ -366,7 +434,7 @@ template <typename XT, typename YT>
 int launch_wide(const cm_layernorm_args &a, bool bwd) {
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     if (!bwd) {
-        hipLaunchKernelGGL((ln_fwd_wide_kernel<XT, YT>), dim3((unsigned)(a.rows < 4096 ? a.rows : 4096)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((ln_fwd_wide_kernel<XT, YT>), dim3((unsigned)(a.rows < 2048 ? a.rows : 2048)), dim3(256), 0, st, a);
         return cm_launch_status("cm_layernorm_fwd");
     }
     const int nblk = (int)(a.rows < BWD_BLOCKS ? a.rows : BWD_BLOCKS);
