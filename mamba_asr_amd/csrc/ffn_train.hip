@@ -166,13 +166,13 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
     }
     if (!p.dbias_part) return;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+    for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = acc[k];   // [k][thread]: consecutive threads on consecutive banks (was 8-way conflicts)
     __syncthreads();
     if (live && tr == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float s = 0.f;
-            for (int j = 0; j < rp; ++j) s += red[(j * vpr + tc) * 8 + k];
+            for (int j = 0; j < rp; ++j) s += red[k * 256 + j * vpr + tc];
             p.dbias_part[(int64_t)blockIdx.x * p.dim + c + k] = s;
         }
     }
@@ -244,13 +244,13 @@ __global__ __launch_bounds__(256) void bias_glu_bwd_kernel(const cm_ffn_elem_arg
     }
     if (!p.dbias_part) return;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) red[threadIdx.x * 16 + k] = acc[k];
+    for (int k = 0; k < 16; ++k) red[k * 256 + threadIdx.x] = acc[k];  // [k][thread] (PMC: 86 % of this kernel's LDS cycles were bank conflicts)
     __syncthreads();
     if (live && tr == 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             float s = 0.f;
-            for (int j = 0; j < rp; ++j) s += red[(j * vpr + tc) * 16 + k];
+            for (int j = 0; j < rp; ++j) s += red[k * 256 + j * vpr + tc];
             p.dbias_part[(int64_t)blockIdx.x * 2 * p.dim + (k < 8 ? c + k : p.dim + c + k - 8)] = s;
         }
     }
