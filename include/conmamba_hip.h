@@ -440,7 +440,8 @@ int cm_reflect_pad_tf(const void *src, void *dst, int32_t batch, int32_t time, i
  * ------------------------------------------------------------------------------------- */
 typedef struct cm_wgrad_args {
     int32_t rows, m, n;
-    int32_t variant;             /* 0: the library picks; 1: tiles travel through registers; 2: global -> LDS directly (LDS-DMA) */
+    int32_t variant;             /* 0: the library picks; 1: tiles travel through registers (2 buffers); 2: global -> LDS directly
+                                    (LDS-DMA) through a 4-stage ring, three 32-row steps in flight; 3: LDS-DMA, 2 buffers of 64 rows */
     const void *a, *b;
     int64_t lda, ldb;
     float *out;

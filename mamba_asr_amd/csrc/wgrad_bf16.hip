@@ -163,6 +163,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const cm_wgrad_args p, co
                 out[(int64_t)(m0 + mw * 64 + i * 16 + 4 * g + r) * p.n + n0 + nw * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
 }
 
+// Deeper pipeline for the LDS-DMA form (PMC of the training step: the two-buffer kernel ran at 17 % MFMA busy with 23 % of wave
+// cycles waiting -- a step's rows are requested ONE 0.25 us compute step ahead of their use against ~1-2 us of memory latency, and
+// two workgroups x one outstanding step = 64 KB in flight per CU).  Here: 32-row steps, a ring of NST = 4 LDS stages (64 KB), three
+// steps (48 KB per workgroup) in flight; per step a counted s_waitcnt vmcnt (the wave's own pieces of the oldest step), ONE raw
+// s_barrier (everyone's pieces have landed, and everyone is done with the stage the next request overwrites), the request for
+// step + 3, then the step's 16 MFMAs per wave.  Requests past the chunk's end address rows outside the descriptors: they write zeros and
+// keep the counts uniform.
+constexpr int KB2 = 32, NST = 4, STAGE_BYTES = KB2 * 256;           // one operand's (32 rows x 128 columns) image
+
+// One LDS-DMA instruction, issued where it is written and invisible to the compiler's wait-count pass: through the builtin, hipcc
+// orders the LDS write against the following ds_reads with s_waitcnt vmcnt(0), i.e. it drains the whole ring every step.  The
+// descriptor is built by hand (raw buffer, num_records bytes from base); M0 = the wave-uniform LDS destination, restored behind.
+__device__ __forceinline__ u32x4 raw_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(const u32x4 rsrc, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_pipe_kernel(const cm_wgrad_args p, const wgrad_plan pl) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST][2][STAGE_BYTES];     // [stage][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = wave >> 1, nw = wave & 1;
+    const int tiles_n = p.n / TN;
+    const int ntile = (p.m / TM) * tiles_n, total = gridDim.x;
+    int id = blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);  // a chunk's tiles on one XCD
+    const int tile = id % ntile, ks = id / ntile;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    const int k_lo = ks * pl.chunk, k_hi = min(p.rows, k_lo + pl.chunk);
+    const u32x4 ra = raw_rsrc(p.a, (uint32_t)((int64_t)k_hi * p.lda * 2)), rb = raw_rsrc(p.b, (uint32_t)((int64_t)k_hi * p.ldb * 2));
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(&lds[0][0][0]);      // the LDS offset is the low half of the flat address
+    // a step's 8 pieces per operand (4 rows each): this wave fills pieces 2 wave, 2 wave + 1; lane -> row 4 piece + lane / 16, IMAGE chunk
+    // lane % 16 = logical chunk ^ swizzle(row)
+    int go_a[2], go_b[2], lo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pi = 2 * wave + i, row = 4 * pi + (lane >> 4);
+        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        lo[i] = pi * 1024;
+        go_a[i] = (int)(((int64_t)(k_lo + row) * p.lda + m0 + ch * 8) * 2);
+        go_b[i] = (int)(((int64_t)(k_lo + row) * p.ldb + n0 + ch * 8) * 2);
+    }
+    const int step_a = (int)(p.lda * KB2 * 2), step_b = (int)(p.ldb * KB2 * 2);
+    const int nstep = (k_hi - k_lo + KB2 - 1) / KB2;
+    auto request = [&](int t) {                                      // 4 LDS-DMA instructions per wave; steps >= nstep read zeros
+        const int st = t % NST;
+        const bool in = t < nstep;                                   // (past the end: offsets that are out of range whatever the stride)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t dst = lds0 + (uint32_t)(st * 2 * STAGE_BYTES) + (uint32_t)__builtin_amdgcn_readfirstlane(lo[i]);
+            dma16(ra, dst, in ? go_a[i] : 0x7ffffff0, in ? t * step_a : 0);
+            dma16(rb, dst + STAGE_BYTES, in ? go_b[i] : 0x7ffffff0, in ? t * step_b : 0);
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int tr_a[4][2], tr_b[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 8 * g + 4 * h + q;
+            tr_a[t][h] = img_off(row, 2 * (mw * 4 + t) + (pp >> 1)) + 8 * (pp & 1);
+            tr_b[t][h] = img_off(row, 2 * (nw * 4 + t) + (pp >> 1)) + 8 * (pp & 1);
+        }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) request(t);
+    for (int t = 0; t < nstep; ++t) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // this wave's 4 pieces of step t (8 of steps t + 1, t + 2 may be in flight)
+        __builtin_amdgcn_s_barrier();                                // everyone's pieces of step t are in LDS; everyone has read stage (t - 1) % NST
+        request(t + NST - 1);                                        // -> stage (t - 1) % NST
+        const int st = t % NST;
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x4 a0 = tr_read(lds[st][0], tr_a[i][0]), a1 = tr_read(lds[st][0], tr_a[i][1]);
+            const bf16x4 b0 = tr_read(lds[st][1], tr_b[i][0]), b1 = tr_read(lds[st][1], tr_b[i][1]);
+            fa[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            fb[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the zero-filling requests past the end have landed before the LDS is released
+    float *out = p.workspace + (int64_t)ks * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(int64_t)(m0 + mw * 64 + i * 16 + 4 * g + r) * p.n + n0 + nw * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+}
+
 inline wgrad_plan plan_for(int rows, int m, int n) {
     const int tiles = (m / TM) * (n / TN);
     int ks = (512 + tiles - 1) / tiles;
@@ -195,11 +302,12 @@ extern "C" int cm_wgrad_bf16(const cm_wgrad_args *args) {
     const wgrad_plan pl = plan_for(a.rows, a.m, a.n);
     CM_REQUIRE(a.workspace_floats >= (int64_t)pl.ksplit * a.m * a.n, CM_EINVAL, "wgrad_bf16: workspace smaller than cm_wgrad_workspace_floats()");
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
-    // few output tiles (256 x 256, 512 x 256): register staging measured faster than LDS-DMA (20.0 / 23.3 vs 23.6 / 26.7 us at 32 k rows);
-    // 1024 x 256 and larger: LDS-DMA (32.2 vs 33.2, 80.8 vs 89.7 us)
-    const bool regs = a.variant == 1 || (a.variant == 0 && (a.m / TM) * (a.n / TN) <= 8);
+    // measured at 32 k rows, fold included (us; 1024x256 / 256x256 / 512x256 / 1024x1024): 4-stage LDS-DMA ring 30.2 / 19.5 / 22.4 / 76.1,
+    // 2-buffer LDS-DMA 31.6 / 23.4 / 26.8 / 86.9, through registers 32.9 / 19.7 / 23.0 / 91.4 -> the ring unless asked otherwise
+    const bool regs = a.variant == 1;
     if (regs) hipLaunchKernelGGL(wgrad_kernel<false>, dim3((a.m / TM) * (a.n / TN) * pl.ksplit), dim3(256), 0, st, a, pl);
-    else hipLaunchKernelGGL(wgrad_kernel<true>, dim3((a.m / TM) * (a.n / TN) * pl.ksplit), dim3(256), 0, st, a, pl);
+    else if (a.variant == 3) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((a.m / TM) * (a.n / TN) * pl.ksplit), dim3(256), 0, st, a, pl);
+    else hipLaunchKernelGGL(wgrad_pipe_kernel, dim3((a.m / TM) * (a.n / TN) * pl.ksplit), dim3(256), 0, st, a, pl);
     if (int rc = cm_launch_status("cm_wgrad_bf16")) return rc;
     return cm_sum_leading(a.workspace, a.out, pl.ksplit, (int64_t)a.m * a.n, CM_F32, CM_F32, a.stream);
 }

@@ -669,7 +669,7 @@ def test_reflect_pad_tf_forward_and_backward(shape, dtype, pad):
 
 @pytest.mark.parametrize("rows,m,n", [(64, 128, 128), (1000, 256, 128), (777, 128, 384), (4100, 1024, 256), (32000, 256, 1024)])
 @pytest.mark.parametrize("strided", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_wgrad_bf16_against_fp64(rows, m, n, strided, variant):
     """cm_wgrad_bf16 (split-K over row chunks, both operands transposed on the way out of LDS) against a^T b in fp64 on the same
     bf16 values; operands as column slices of wider tensors (the gradients of the concatenated BiMamba tensors); run twice: same bits."""

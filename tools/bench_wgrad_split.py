@@ -33,5 +33,5 @@ if __name__ == "__main__":
             k = rows // nb
             f = lambda: ops.sum_leading(torch.bmm(A.view(nb, k, M).transpose(1, 2), B.view(nb, k, N)))
             line += f" {nb:3d} chunks {timeit(f):6.1f} us |"
-        line += f" one GEMM {timeit(lambda: torch.mm(A.t(), B)):6.1f} us | cm_wgrad_bf16 LDS-DMA {timeit(lambda: ops.wgrad(A, B, variant=2)):6.1f} us, through registers {timeit(lambda: ops.wgrad(A, B, variant=1)):6.1f} us"
+        line += f" one GEMM {timeit(lambda: torch.mm(A.t(), B)):6.1f} us | cm_wgrad_bf16 4-stage LDS-DMA ring {timeit(lambda: ops.wgrad(A, B, variant=2)):6.1f} us, 2-buffer LDS-DMA {timeit(lambda: ops.wgrad(A, B, variant=3)):6.1f} us, through registers {timeit(lambda: ops.wgrad(A, B, variant=1)):6.1f} us"
         print(line, flush=True)
