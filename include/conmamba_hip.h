@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 8
+#define CM_ABI_VERSION 9
 
 /* error codes */
 #define CM_OK            0

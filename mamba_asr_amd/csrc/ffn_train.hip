@@ -1,7 +1,8 @@
 // ffn_train.hip — the element-wise stages of a feed-forward module's TRAINING step on (rows, features) tensors, one kernel per
 // stage and direction (the reference leaves them to torch: Linear -> activation -> Dropout -> Linear -> Dropout -> 0.5 x + residual,
 // reference modules/Conmamba.py:597-617, 638-648: eight element-wise launches forward, ten backward per module and micro-batch):
-//   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))                    (a: GEMM output without bias; act: none | GELU(erf))
+//   cm_bias_act_dropout_fwd   y = dropout(act(a + bias))                    (a: GEMM output without bias; act: none | GELU: the erf form
+//                             for fp32 results, cm_common.h's x sigmoid(x P(x^2)) form where the result is rounded to bf16)
 //                             or, with `res`:  y = res + alpha * dropout(a + bias)   (fp32 residual stream)
 //   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias);  dbias = column sums of da, through per-workgroup
 //                             partial rows + a fixed-order second pass (deterministic)

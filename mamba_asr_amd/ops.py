@@ -180,19 +180,14 @@ def invalidate_caches(module: torch.nn.Module) -> None:
     THROUGH ``p.data`` (``p.data.copy_()``, EMA / SWA code, vector_to_parameters) are not -- call this after them.
     load_state_dict calls it by itself (hook installed by asr.ConMambaASR)."""
     for p in module.parameters():
-        if hasattr(p, "_cm_pack"):
-            del p._cm_pack
-        if hasattr(p, "_cm_pack_t"):
-            del p._cm_pack_t
+        for attr in ("_cm_pack", "_cm_pack_t", "_cm_cast"):
+            if hasattr(p, attr):
+                try:
+                    delattr(p, attr)
+                except AttributeError:
+                    pass
     for m in module.modules():
-        if hasattr(m, "_cm_plist"):
-            del m._cm_plist
-        if hasattr(p, "_cm_cast"):
-            try:
-                del p._cm_cast
-            except AttributeError:
-                pass
-    for m in module.modules():
+        m.__dict__.pop("_cm_plist", None)
         for attr in ("_cm_fused_cache", "_cm_frontend_cache"):
             if hasattr(m, attr):
                 delattr(m, attr)
