@@ -455,9 +455,12 @@ def main():
         del model
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
-        tl = run_train(at, cfg, dev, rank, world, False, emit_line=False)
-        extras["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "peak_mem_gib", "optimizer_steps", "roofline")}
-        extras["train"]["workload"] = tl["config"]["workload"]
+        try:                                                                         # an extra key must not take the headline line down with it
+            tl = run_train(at, cfg, dev, rank, world, False, emit_line=False)
+            extras["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "peak_mem_gib", "optimizer_steps", "roofline")}
+            extras["train"]["workload"] = tl["config"]["workload"]
+        except Exception as exc:                                                     # noqa: BLE001 -- reported in the line, never silent
+            extras["train"] = {"error": f"{type(exc).__name__}: {exc}"[:500]}
 
     if rank == 0:
         # whole-path roofline position (SURVEY §8d canonical bytes per audio frame, bf16)
