@@ -6,7 +6,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = [int(r["Calls"]) for r in rows if "scan_rows_fwd_kernel" in r["Name"]][0] / int(sys.argv[2] if len(sys.argv) > 2 else 18)
 bad = ("naive_conv", "ck16", "ck::", "kernel_batched_gemm_xdlops_bwd_weight")
-grp = {"scan fwd": ("scan_rows_fwd",), "scan bwd": ("scan_rows_bwd",), "wgrad + folds": ("wgrad_kernel", "sum_leading"), "library GEMMs": ("Cijk",),
+grp = {"scan fwd": ("scan_rows_fwd",), "scan bwd": ("scan_rows_bwd",), "wgrad + folds": ("wgrad_", "sum_leading"), "library GEMMs": ("Cijk",),
        "ffn fused fwd": ("ffn_fused",), "ffn fused bwd": ("ffn_bwd",), "module element-wise": ("bias_act", "bias_glu", "colsum"), "LayerNorm": ("ln_",),
        "conv kernels": ("conv_cl", "conv_xproj", "dwconv"), "CNN front end": ("igemm", "reflect", "leaky", "SubTensor"), "CTC": ("ctc_",),
        "torch element-wise / reduce / copy": ("at::native", "copyBuffer", "fillBuffer")}
