@@ -844,7 +844,8 @@ typedef struct cm_ffn_args {
     float       *stats_out;             /* (2, rows) fp32 or NULL: mean, 1/std of LN(x)'s rows, as cm_layernorm_bwd reads them */
     int32_t layout;                     /* 0: w1 / w2 / proj_w in cm_ffn_pack_weights' image (16-row x 32-column tiles, v_mfma_f32_16x16x32_bf16);
                                            1: in cm_ffn_pack_weights32's (32 x 16 tiles, v_mfma_f32_32x32x16_bf16; inference forward only) */
-    int32_t reserved0;
+    int32_t tokens;                     /* layout 1: tokens per workgroup, 0 / 64 or 32 (32: for launches of fewer than ~400 64-token
+                                           workgroups, which leave CUs idle) */
 } cm_ffn_args;
 
 int cm_ffn_fused(const cm_ffn_args *args);

@@ -257,7 +257,7 @@ class FfnArgs(C.Structure):
         ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
         ("proj_dim", i32), ("stream", vp), ("proj_w", vp), ("proj_b", fp), ("proj_out", vp),
         ("pre_out", vp), ("xn_out", vp), ("p1", C.c_float), ("p2", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
-        ("stats_out", fp), ("layout", i32), ("reserved0", i32),
+        ("stats_out", fp), ("layout", i32), ("tokens", i32),
     ]
 
 

@@ -633,6 +633,7 @@ extern "C" int cm_ffn_fused(const cm_ffn_args *args) {
     const bool train = a.pre_out || a.xn_out || a.stats_out || a.p1 > 0.f || a.p2 > 0.f;
     CM_REQUIRE(a.layout == 0 || a.layout == 1, CM_EINVAL, "ffn_fused: layout must be 0 or 1");
     CM_REQUIRE(a.layout == 0 || !train, CM_EUNSUPPORTED, "ffn_fused: the training forward takes layout 0 weights");
+    CM_REQUIRE(a.tokens == 0 || a.tokens == 64 || (a.tokens == 32 && a.layout == 1), CM_EINVAL, "ffn_fused: tokens must be 0 / 64, or 32 with layout 1");
     if (a.layout == 1) return cm_ffn_fused32_launch(a);
     if (train) {
         CM_REQUIRE(a.x_out && !a.addend && !a.n1_g && !a.n2_g && !a.proj_w && !a.h_out, CM_EINVAL,

@@ -20,14 +20,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-constexpr int D = 256, TOK = 64, NT = 256, XS = 264, CH = 256;
+constexpr int D = 256, NT = 256, XS = 264, CH = 256;
 constexpr int PF = 8;         // weight-fragment ring depth in k16-steps (= the 4 k32-steps of the 16x16x32 kernel)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
 
-template <bool ADD, bool PROJ>
+// TOK: tokens per workgroup, 64 or 32.  32 (cm_ffn_args.tokens = 32) is for launches that leave CUs idle at 64: 16 k rows are 250
+// workgroups on 512 slots (SURVEY's 16 x 40 s; per part of the two-stream encoder half of that), each streaming the same 1 MB of weights
+// as a 64-token one -- twice the weight stream per token, bought back by a chip that is full.
+template <bool ADD, bool PROJ, int TOK>
 __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p) {
+    constexpr int NB = TOK / 32;                                  // 32-token tiles per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
     uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab
@@ -77,15 +81,16 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         return v;
     };
     {
-        float4 v[4][4];
+        constexpr int RD = TOK / 16;                              // rounds of 4 tokens per wave (wave w owns tokens (TOK / 4) w ..)
+        float4 v[RD][4];
 #pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {
-            const int tok = min(t0 + wave * 16 + rd * 4 + lq, M - 1);
+        for (int rd = 0; rd < RD; ++rd) {
+            const int tok = min(t0 + wave * (TOK / 4) + rd * 4 + lq, M - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[rd][i] = load_x4(tok, (l15 + 16 * i) * 4);
         }
 #pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {
+        for (int rd = 0; rd < RD; ++rd) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) s += (v[rd][i].x + v[rd][i].y) + (v[rd][i].z + v[rd][i].w);
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
                 q = fmaf(v[rd][i].x, v[rd][i].x, fmaf(v[rd][i].y, v[rd][i].y, fmaf(v[rd][i].z, v[rd][i].z, fmaf(v[rd][i].w, v[rd][i].w, q))));
             }
             const float rstd = rsqrtf(cm_group_sum<16>(q) * (1.f / D) + p.pre_eps);
-            uint16_t *dst = xn + (wave * 16 + rd * 4 + lq) * XS;
+            uint16_t *dst = xn + (wave * (TOK / 4) + rd * 4 + lq) * XS;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = (l15 + 16 * i) * 4;
@@ -113,41 +118,41 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
     lds_barrier();
 
     // ---- main loop over hidden slabs
-    f32x16 acc2[2][2];
+    f32x16 acc2[2][NB];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[mb][nb][e] = 0.f;
     const uint16_t *xfrag = xn + l31 * XS + h * 8;                // + nb * 32 rows, + 16 columns per k16-step
     const uint16_t *hfrag = hc + l31 * XS + h * 8;
     const int f0 = wave * 64 + 4 * h;                             // + 32 mb + 8 g + i
     uint16_t *hdst = hc + l31 * XS + f0;
-    auto read_frags = [&](const uint16_t *base, int ks, bf16x8(&bf)[2]) {
+    auto read_frags = [&](const uint16_t *base, int ks, bf16x8(&bf)[NB]) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bf[nb] = *reinterpret_cast<const bf16x8 *>(base + nb * 32 * XS + ks * 16);
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const bf16x8 *>(base + nb * 32 * XS + ks * 16);
     };
     auto slab = [&](const int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        f32x16 acc1[2][2];
+        f32x16 acc1[2][NB];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc1[mb][nb][e] = 0.f;
-        bf16x8 bfa[2], bfb[2];
+        bf16x8 bfa[NB], bfb[NB];
         read_frags(xfrag, 0, bfa);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {                               // GEMM 1: this wave's 64 hidden units x 64 tokens, K = 256
-            bf16x8(&cur)[2] = (s & 1) ? bfb : bfa;
-            bf16x8(&nxt)[2] = (s & 1) ? bfa : bfb;
+            bf16x8(&cur)[NB] = (s & 1) ? bfb : bfa;
+            bf16x8(&nxt)[NB] = (s & 1) ? bfa : bfb;
             if (s + 1 < 16) read_frags(xfrag, s + 1, nxt);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc1[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc1[mb][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc1[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc1[mb][nb], 0, 0, 0);
             wload(c, s + PF, wq[s % PF]);
             __builtin_amdgcn_sched_barrier(0);                    // keep the refill HERE (see ffn_fused.hip)
         }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *reinterpret_cast<const float4 *>(b1s + c * CH + f0 + mb * 32 + g * 8);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NB; ++nb) {
                     uint2 pk;
                     pk.x = cm_gelu_bf16_pack2(acc1[mb][nb][4 * g + 0] + bv.x, acc1[mb][nb][4 * g + 1] + bv.y);
                     pk.y = cm_gelu_bf16_pack2(acc1[mb][nb][4 * g + 2] + bv.z, acc1[mb][nb][4 * g + 3] + bv.w);
@@ -169,13 +174,13 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         read_frags(hfrag, 0, bfa);
 #pragma unroll
         for (int s = 16; s < 32; ++s) {                              // GEMM 2: 64 output features x 64 tokens, K = this slab
-            bf16x8(&cur)[2] = (s & 1) ? bfb : bfa;
-            bf16x8(&nxt)[2] = (s & 1) ? bfa : bfb;
+            bf16x8(&cur)[NB] = (s & 1) ? bfb : bfa;
+            bf16x8(&nxt)[NB] = (s & 1) ? bfa : bfb;
             if (s + 1 < 32) read_frags(hfrag, s + 1 - 16, nxt);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc2[mb][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc2[mb][nb], 0, 0, 0);
             if (s + PF < 32) wload(c, s + PF, wq[s % PF]);
             else if constexpr (!LAST) wload(c + 1, s + PF - 32, wq[s % PF]);
             __builtin_amdgcn_sched_barrier(0);
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
     slab(nch - 1, std::true_type{});
 
     // ---- residual rows (whole rows through LDS into the accumulator layout, requested after the last GEMM: ffn_fused.hip)
-    float r[2][2][16];                                            // [token tile][feature band][8 g + ... register order of the accumulator]
+    float r[NB][2][16];                                            // [token tile][feature band][8 g + ... register order of the accumulator]
     constexpr int SR = 260;
     float *stg = reinterpret_cast<float *>(smem);
     {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         }
         lds_barrier();
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         for (int g = 0; g < 4; ++g) {
             const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + f0 + mb * 32 + g * 8);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 r[nb][mb][4 * g + 0] = fmaf(p.alpha, acc2[mb][nb][4 * g + 0] + bv.x, r[nb][mb][4 * g + 0]);
                 r[nb][mb][4 * g + 1] = fmaf(p.alpha, acc2[mb][nb][4 * g + 1] + bv.y, r[nb][mb][4 * g + 1]);
                 r[nb][mb][4 * g + 2] = fmaf(p.alpha, acc2[mb][nb][4 * g + 2] + bv.z, r[nb][mb][4 * g + 2]);
@@ -227,25 +232,25 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
             }
         }
     // sum over a token's 256 features: 32 in-lane, the two feature halves (lane ^ 32), 4 waves (through LDS)
-    auto token_sums = [&](float (&v)[2]) {
+    auto token_sums = [&](float (&v)[NB]) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) v[nb] += __shfl_xor(v[nb], 32, 64);
+        for (int nb = 0; nb < NB; ++nb) v[nb] += __shfl_xor(v[nb], 32, 64);
         lds_barrier();                                            // previous use of red is over
         if (h == 0) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) red[wave * TOK + nb * 32 + l31] = v[nb];
+            for (int nb = 0; nb < NB; ++nb) red[wave * TOK + nb * 32 + l31] = v[nb];
         }
         lds_barrier();
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const int t = nb * 32 + l31;
             v[nb] = (red[t] + red[TOK + t]) + (red[2 * TOK + t] + red[3 * TOK + t]);
         }
     };
     auto layer_norm = [&](const float *gw, const float *bw, float eps) {
-        float s[2];
+        float s[NB];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             s[nb] = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -253,9 +258,9 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
                 for (int e = 0; e < 16; e += 4) s[nb] += (r[nb][mb][e] + r[nb][mb][e + 1]) + (r[nb][mb][e + 2] + r[nb][mb][e + 3]);
         }
         token_sums(s);
-        float q[2];
+        float q[NB];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             s[nb] *= (1.f / D);
             q[nb] = 0.f;
 #pragma unroll
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
                 const float4 gv = *reinterpret_cast<const float4 *>(gw + f0 + mb * 32 + g * 8);
                 const float4 bv = *reinterpret_cast<const float4 *>(bw + f0 + mb * 32 + g * 8);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NB; ++nb) {
                     const float rstd = rsqrtf(q[nb] * (1.f / D) + eps);
                     r[nb][mb][4 * g + 0] = fmaf((r[nb][mb][4 * g + 0] - s[nb]) * rstd, gv.x, bv.x);
                     r[nb][mb][4 * g + 1] = fmaf((r[nb][mb][4 * g + 1] - s[nb]) * rstd, gv.y, bv.y);
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         constexpr int SS = 260;
         lds_barrier();                                            // (also: the staged residual rows above have been read by every wave)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
         lds_barrier();                                            // the staged stream rows have left / the last GEMM's reads are over
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -326,24 +331,24 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
         uint16_t *po = reinterpret_cast<uint16_t *>(p.proj_out);
         const int nps = p.proj_dim / 256;
         for (int ps = 0; ps < nps; ++ps) {
-            f32x16 acc[2][2];
+            f32x16 acc[2][NB];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
-            bf16x8 bfa[2], bfb[2];
+            bf16x8 bfa[NB], bfb[NB];
             read_frags(xfrag, 0, bfa);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                bf16x8(&cur)[2] = (s & 1) ? bfb : bfa;
-                bf16x8(&nxt)[2] = (s & 1) ? bfa : bfb;
+                bf16x8(&cur)[NB] = (s & 1) ? bfb : bfa;
+                bf16x8(&nxt)[NB] = (s & 1) ? bfa : bfb;
                 if (s + 1 < 16) read_frags(xfrag, s + 1, nxt);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc[mb][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % PF][mb], cur[nb], acc[mb][nb], 0, 0, 0);
                 if (s + PF < 16) pload(ps, s + PF, wq[s % PF]);
                 else if (ps + 1 < nps) pload(ps + 1, s + PF - 16, wq[s % PF]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
                     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.proj_b) bv = *reinterpret_cast<const float4 *>(p.proj_b + ps * 256 + f0 + mb * 32 + g * 8);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
+                    for (int nb = 0; nb < NB; ++nb) {
                         uint2 pk;
                         pk.x = pack2(acc[mb][nb][4 * g + 0] + bv.x, acc[mb][nb][4 * g + 1] + bv.y);
                         pk.y = pack2(acc[mb][nb][4 * g + 2] + bv.z, acc[mb][nb][4 * g + 3] + bv.w);
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused32_kernel(const cm_ffn_args p)
     if (p.h_out) {
         if (p.n2_g) layer_norm(p.n2_g, p.n2_b, p.n2_eps);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const int tok = t0 + nb * 32 + l31;
             if (tok < M) {
 #pragma unroll
@@ -411,19 +416,19 @@ __global__ void ffn_pack32_kernel(const uint16_t *__restrict__ w, uint16_t *__re
     *reinterpret_cast<uint4 *>(out + piece * 8) = *reinterpret_cast<const uint4 *>(w + (int64_t)r * K + k);
 }
 
-template <bool ADD, bool PROJ>
+template <bool ADD, bool PROJ, int TOK>
 int launch32(const cm_ffn_args &a) {
     const size_t smem = (size_t)2 * TOK * XS * sizeof(uint16_t) + (size_t)4 * TOK * sizeof(float) + (size_t)a.hidden * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused32_kernel<ADD, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused32_kernel<ADD, PROJ, TOK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             cm_set_error("ffn_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((ffn_fused32_kernel<ADD, PROJ>), dim3((a.rows + TOK - 1) / TOK), dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
+    hipLaunchKernelGGL((ffn_fused32_kernel<ADD, PROJ, TOK>), dim3((a.rows + TOK - 1) / TOK), dim3(NT), smem, reinterpret_cast<hipStream_t>(a.stream), a);
     return cm_launch_status("cm_ffn_fused(32x32x16)");
 }
 
@@ -441,6 +446,10 @@ extern "C" int cm_ffn_pack_weights32(const void *w, int32_t rows, int32_t cols, 
 
 // called by cm_ffn_fused (ffn_fused.hip) after its argument checks when args->layout == 1
 int cm_ffn_fused32_launch(const cm_ffn_args &a) {
-    if (a.proj_w) return a.addend ? launch32<true, true>(a) : launch32<false, true>(a);
-    return a.addend ? launch32<true, false>(a) : launch32<false, false>(a);
+    if (a.tokens == 32) {
+        if (a.proj_w) return a.addend ? launch32<true, true, 32>(a) : launch32<false, true, 32>(a);
+        return a.addend ? launch32<true, false, 32>(a) : launch32<false, false, 32>(a);
+    }
+    if (a.proj_w) return a.addend ? launch32<true, true, 64>(a) : launch32<false, true, 64>(a);
+    return a.addend ? launch32<true, false, 64>(a) : launch32<false, false, 64>(a);
 }

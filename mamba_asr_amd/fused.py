@@ -38,6 +38,9 @@ class _LayerCache:
         if ops.ffn_supported(self.ffn1["w1"].shape[1], self.ffn1["w1"].shape[0], dtype) and self.ffn1["w1"].is_cuda:
             for q in (self.ffn1, self.ffn2):                       # cm_ffn_fused's fragment-tiled weight images
                 q["w1p"], q["w2p"] = ops.PackedWeight(q["w1"], ops.FFN_LAYOUT), ops.PackedWeight(q["w2"], ops.FFN_LAYOUT)
+                # the 32 x 16 tile image for small launches (32-token workgroups exist on the 32x32x16 kernel only)
+                if ops.SMALL_FFN_ROWS > 0:
+                    q["w1s"], q["w2s"] = (q["w1p"], q["w2p"]) if ops.FFN_LAYOUT == 32 else (ops.PackedWeight(q["w1"], 32), ops.PackedWeight(q["w2"], 32))
         self.norm1 = (f(layer.norm1.norm.weight), f(layer.norm1.norm.bias), layer.norm1.norm.eps)
         self.norm2 = (f(layer.norm2.norm.weight), f(layer.norm2.norm.bias), layer.norm2.norm.eps)
         m = layer.mamba
@@ -47,6 +50,8 @@ class _LayerCache:
         if (USE_FFN_INPROJ and dtype == torch.bfloat16 and self.in_proj.is_cuda and self.in_proj.shape[1] == 256
                 and self.in_proj.shape[0] % 256 == 0 and self.in_proj.shape[0] <= 4096 and m.in_proj.bias is None):
             self.in_packed = ops.PackedWeight(self.in_proj, ops.FFN_LAYOUT)   # streamed by cm_ffn_fused's projection epilogue only
+            if ops.SMALL_FFN_ROWS > 0:
+                self.in_packed_s = self.in_packed if ops.FFN_LAYOUT == 32 else ops.PackedWeight(self.in_proj, 32)
         self.in_bias = None if m.in_proj.bias is None else c(m.in_proj.bias)
         half = 0.5 if m.if_devide_out else 1.0
         self.out_cat = c(torch.cat([m.out_proj.weight, m.out_proj.weight], dim=1) * half)      # (D, 2E)
@@ -228,8 +233,15 @@ def _layer_forward_ffn_fused(c, x, batch, seqlen, dtype, final_ln=None):
     """layer_forward with both feed-forward modules on cm_ffn_fused (bf16, d_model 256)."""
     D = x.shape[-1]
     f1, f2 = c.ffn1, c.ffn2
+    if 0 < x.shape[0] <= ops.SMALL_FFN_ROWS and "w1s" in f1:
+        # a launch this small leaves CUs idle at 64 tokens per workgroup: the 32-token form of the 32x32x16 kernel
+        f1 = dict(f1, w1p=f1["w1s"], w2p=f1["w2s"])
+        f2 = dict(f2, w1p=f2["w1s"], w2p=f2["w2s"])
+        inp = getattr(c, "in_packed_s", None)
+    else:
+        inp = c.in_packed
     if c.in_packed is not None:                                                                                # x += 0.5 ffn1 ; norm1 ; in_proj
-        _, xz = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1, proj_w=c.in_packed)
+        _, xz = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1, proj_w=inp)
         y = bimamba_fused(c, None, batch, seqlen, xz=xz)
     else:
         _, h = ops.ffn_fused(x, f1["ln"], f1["w1p"], f1["b1f"], f1["w2p"], f1["b2f"], alpha=0.5, norm2=c.norm1)   # x += 0.5 ffn1 ; norm1

@@ -1371,6 +1371,10 @@ def ffn_supported(d_model: int, hidden: int, dtype) -> bool:
 # cm_ffn_fused's inference forward on v_mfma_f32_32x32x16_bf16 (csrc/ffn_fused32.hip, weights in the 32 x 16 tile image) instead of
 # 16x16x32 (csrc/ffn_fused.hip): CM_FFN_MFMA32=1
 FFN_LAYOUT = 32 if os.environ.get("CM_FFN_MFMA32", "0") == "1" else 16
+# CM_FFN_SMALL_ROWS=N: launches of at most N rows run the 32x32x16 kernel with 32-token workgroups (fused.py then keeps both weight
+# images).  Off by default: alone it wins below ~12 k rows (8000 rows: 28.5 / 19.4 vs 34.4 / 24.4 us; 16000: 42.8 / 31.2 vs 40.5 / 28.8),
+# in the encoder at 16 x 40 s (two parts of 8000 rows whose kernels share the chip) it changes nothing (4.78 vs 4.78 ms)
+SMALL_FFN_ROWS = int(os.environ.get("CM_FFN_SMALL_ROWS", "0"))
 
 
 class PackedWeight:
@@ -1393,7 +1397,7 @@ class PackedWeight:
 
 
 def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0, norm1=None, norm2=None,
-              x_out=None, want_h=True, h_dtype=torch.bfloat16, proj_w=None, proj_b=None, proj_out=None, train=None):
+              x_out=None, want_h=True, h_dtype=torch.bfloat16, proj_w=None, proj_b=None, proj_out=None, train=None, tokens=None):
     """Whole feed-forward module on the fp32 residual stream (cm_ffn_fused):
         xin = x + add_scale*addend;  r = xin + alpha*(W2 gelu(W1 LN_pre(xin) + b1) + b2);  r = LN1(r) if norm1;
         x_out <- r (x itself when x_out is None);  returns h = LN2(r) (or r when norm2 is None) in h_dtype if want_h.
@@ -1427,6 +1431,9 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
     a.x, a.pre_g, a.pre_b, a.pre_eps = _ptr(x), _ptr(pre_norm[0]), _ptr(pre_norm[1]), float(pre_norm[2])
     a.w1, a.b1, a.w2, a.b2, a.alpha = _ptr(w1.data), _ptr(b1), _ptr(w2.data), _ptr(b2), float(alpha)
     a.layout = 1 if w1.layout == 32 else 0
+    if w1.layout == 32:
+        # 32-token workgroups when 64-token ones would not fill the chip's 512 workgroup slots
+        a.tokens = int(tokens) if tokens else (32 if rows <= SMALL_FFN_ROWS else 64)
     if addend is not None:
         if addend.dtype != torch.bfloat16 or not addend.is_contiguous() or addend.shape != x.shape:
             raise RuntimeError("ffn_fused: addend must be a contiguous bf16 tensor shaped like x")

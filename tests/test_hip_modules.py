@@ -206,7 +206,7 @@ def test_fused_frontend_and_encoder_match_unfused_and_oracle(dtype):
     (333, 1024, True, True, False, None),                  # FFN 2 of a layer: addend, closing norm2, no h
     (130, 512, True, True, True, torch.float32),           # last layer: + the encoder's final norm, fp32 out
 ])
-@pytest.mark.parametrize("layout", [16, 32])
+@pytest.mark.parametrize("layout", [16, 32, -32])             # -32: layout 32 with 32-token workgroups
 def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt, layout):
     """cm_ffn_fused vs an fp32 restatement with the kernel's rounding points (bf16 GEMM operands, fp32 accumulate); both matrix
     instructions (layout 16: 16x16x32 tiles, csrc/ffn_fused.hip; 32: 32x32x16, csrc/ffn_fused32.hip)."""
@@ -232,8 +232,10 @@ def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt, layout):
     d = lambda t: None if t is None else t.to(DEV)
     dn = lambda p_: None if p_ is None else (p_[0].to(DEV), p_[1].to(DEV), p_[2])
     xg = x.to(DEV)
+    tokens = {16: None, 32: 64, -32: 32}[layout]
+    layout = abs(layout)
     xo, h = ops.ffn_fused(xg, dn(pre), ops.PackedWeight(d(w1), layout), d(b1), ops.PackedWeight(d(w2), layout), d(b2), alpha=0.5, addend=d(add), add_scale=0.7, norm1=dn(nn1),
-                          norm2=dn(nn2), want_h=hdt is not None, h_dtype=hdt or torch.bfloat16)
+                          norm2=dn(nn2), want_h=hdt is not None, h_dtype=hdt or torch.bfloat16, tokens=tokens)
     assert xo.data_ptr() == xg.data_ptr()
     torch.testing.assert_close(xo.cpu(), r, rtol=2e-3, atol=4e-3)
     assert (xo.cpu() - r).abs().mean() < 3e-4
@@ -244,7 +246,7 @@ def test_ffn_fused_kernel(rows, hidden, addend, n1, n2, hdt, layout):
 
 
 @pytest.mark.parametrize("rows,pdim,bias", [(64, 1024, False), (1000, 1024, True), (37, 256, False), (200, 2048, True)])
-@pytest.mark.parametrize("layout", [16, 32])
+@pytest.mark.parametrize("layout", [16, 32, -32])
 def test_ffn_fused_projection_epilogue(rows, pdim, bias, layout):
     """cm_ffn_fused with proj_w: the Linear that consumes h (the BiMamba in_proj, reference bimamba.py:192-200) inside the
     kernel == the kernel's own bf16 h through an fp32 matmul with the same bf16 weight; the stream output is unchanged."""
@@ -258,14 +260,16 @@ def test_ffn_fused_projection_epilogue(rows, pdim, bias, layout):
     pre, n2 = ln(), ln()
     wp, bp = rn(pdim, 256, scale=1 / 16).bfloat16(), (rn(pdim, scale=0.1) if bias else None)
     xa, xb = x.clone(), x.clone()
+    tokens = {16: None, 32: 64, -32: 32}[layout]
+    layout = abs(layout)
     w1, w2 = ops.PackedWeight(w1, layout), ops.PackedWeight(w2, layout)
-    _, h = ops.ffn_fused(xa, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2)
-    _, xz = ops.ffn_fused(xb, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp, layout), proj_b=bp)
+    _, h = ops.ffn_fused(xa, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, tokens=tokens)
+    _, xz = ops.ffn_fused(xb, pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp, layout), proj_b=bp, tokens=tokens)
     assert torch.equal(xa, xb) and xz.shape == (rows, pdim) and xz.dtype == torch.bfloat16
     want = h.float() @ wp.float().t() + (bp if bias else 0.0)
     torch.testing.assert_close(xz.float(), want, rtol=8e-3, atol=8e-3)
     out = torch.empty(rows, pdim, dtype=torch.bfloat16, device=DEV)
-    _, xz2 = ops.ffn_fused(x.clone(), pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp, layout), proj_b=bp, proj_out=out)
+    _, xz2 = ops.ffn_fused(x.clone(), pre, w1, b1, w2, b2, alpha=0.5, norm2=n2, proj_w=ops.PackedWeight(wp, layout), proj_b=bp, proj_out=out, tokens=tokens)
     assert xz2.data_ptr() == out.data_ptr() and torch.equal(out, xz)
 
 
