@@ -48,6 +48,8 @@ def parse():
                     help="forward mode, 1 GPU: skip the extra keys of the line (\"train\": the training micro-batch of --mode train at 32 utterances; "
                          "\"survey_b16\": the forward at SURVEY §8d's 16 x 40 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph-train", action="store_true",
+                    help="--mode train: replay forward + loss + backward of a micro-batch from a hipGraph (brain.Brain graph_steps)")
     ap.add_argument("--streams", type=int, default=None, help="parts / HIP streams of the fused encoder (default: CM_STREAMS or 2)")
     ap.add_argument("--stream-mode", choices=["join", "free", "pair"], default=None,
                     help="join (default): the scan runs once per layer on the whole batch; free: fully independent parts")
@@ -161,13 +163,22 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
     s2s = cfg.num_decoder_layers > 0                          # config 5: Mamba decoder + joint CTC / label-smoothed KL loss
 
     class ASR(Brain):
+        def graph_prologue(self, batch):
+            # --graph-train: Fbank, the running normalisation statistics and SpecAugment (host-side random draws) stay eager;
+            # the captured region starts at the CNN front end with the augmented features as its input
+            wavs, lens, tokens, tlens = batch
+            with torch.no_grad():
+                feats = self.modules["asr"].features(wavs, lens, epoch=0, augment=aug)
+            return (feats, lens, tokens, tlens)
+
         def compute_forward(self, batch, stage):
             wavs, lens, tokens, tlens = batch
             m, a_ = self.modules["asr"], (aug if stage == Stage.TRAIN else None)
+            feats = wavs if wavs.dim() == 3 else None          # (batch, frames, mels): graph_prologue's output
             if s2s:                                            # train_S2S.py:285-320: <bos> + tokens into the decoder
                 bos = torch.cat([torch.ones_like(tokens[:, :1]), tokens], 1)
-                return m.forward_s2s(wavs, lens, bos, epoch=0, augment=a_)
-            return m.forward_ctc(wavs, lens, epoch=0, augment=a_)
+                return m.forward_s2s(wavs, lens, bos, epoch=0, augment=a_, feats=feats)
+            return m.forward_ctc(wavs, lens, epoch=0, augment=a_, feats=feats)
 
         def compute_objectives(self, pred, batch, stage):
             wavs, lens, tokens, tlens = batch
@@ -184,7 +195,8 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
 
     brain = ASR({"asr": model}, opt_class=lambda ps: torch.optim.AdamW(ps, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=5e-4),
                 hparams={"precision": "bf16" if a.dtype == "bf16" else "fp32", "grad_accumulation_factor": a.accum,
-                         "max_grad_norm": 5.0, "noam": sb.NoamScheduler(1e-3, 7500)}, run_opts={"device": str(dev)})
+                         "max_grad_norm": 5.0, "noam": sb.NoamScheduler(1e-3, 7500)},
+                run_opts={"device": str(dev), "graph_steps": bool(a.graph_train)})
     params = [p for p in brain.modules.parameters() if p.requires_grad]
     if use_dist:                                               # also at world 1: the exchange then runs through RCCL alone
         brain.reducer = GradAllReducer(params, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None, algo=a.ddp_algo,
@@ -204,7 +216,7 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
             dist.barrier()
             torch.cuda.synchronize()
 
-    losses = [brain.fit_batch(batch) for _ in range(max(a.warmup, 1))]
+    losses = [brain.fit_batch(batch) for _ in range(max(a.warmup, 3 if a.graph_train else 1))]      # graph mode: eager, capture, first replay
     fence()
     t0 = time.perf_counter()
     exposed = []
@@ -224,6 +236,7 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
     roof = None
     # backward-scan roofline: one more micro-batch on EVERY rank (it may end in the exchange), HIP events on rank 0
     ops.LAUNCH_LOG = [] if rank == 0 else None
+    brain.graph_steps = False                                  # the per-launch event pairs need eager launches
     brain.fit_batch(batch)
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
@@ -254,6 +267,7 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
                 "config": {"workload": f"{cfg.name}: {'S2S' if s2s else 'CTC'} training micro-batch, {a.batch} utterances x {a.frames} frames per GPU, "
                                        f"SpecAugment, grad_accumulation_factor {a.accum}, AdamW + Noam, clip 5.0",
                            "global_batch": world * a.batch, "frames_per_utterance": a.frames,
+                           "launch": "hipGraph replay of forward + loss + backward per micro-batch (exchange, clip, AdamW eager)" if a.graph_train else "eager",
                            "parallelism": f"dp{world}: gradient exchange every {a.accum} micro-batches "
                                           f"({'RCCL ' + (brain.reducer.algo if brain.reducer else '') if use_dist else 'none: single process'})"},
                 "allreduce_bytes_per_optimizer_step": brain.reducer.bytes_per_step() if brain.reducer else 0,
@@ -451,6 +465,7 @@ def main():
         import copy
         at = copy.copy(a)
         at.batch, at.steps, at.warmup, at.accum, at.comm_dtype, at.ddp_algo = 32, 8, 4, 4, "f32", None
+        at.graph_train = not a.no_graph                                              # the micro-batch's fwd + loss + bwd as a hipGraph, as the forward line
         graphed = step = out = None                                                  # release the forward's graph and buffers
         del model
         torch.cuda.empty_cache()
@@ -459,6 +474,7 @@ def main():
             tl = run_train(at, cfg, dev, rank, world, False, emit_line=False)
             extras["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "peak_mem_gib", "optimizer_steps", "roofline")}
             extras["train"]["workload"] = tl["config"]["workload"]
+            extras["train"]["launch"] = tl["config"]["launch"]
         except Exception as exc:                                                     # noqa: BLE001 -- reported in the line, never silent
             extras["train"] = {"error": f"{type(exc).__name__}: {exc}"[:500]}
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 9
+#define CM_ABI_VERSION 10
 
 /* error codes */
 #define CM_OK            0
@@ -393,6 +393,7 @@ int cm_ctc_loss(const cm_ctc_args *args);
  *   cm_bias_act_dropout_bwd   da = alpha * dy * mask / (1 - p) * act'(a + bias)  [I/O dtype];  dbias += column sums of da (fixed order)
  * act: 0 none, 1 GELU (erf form), 2 GLU (a and da are (rows, 2 dim), bias / dbias (2 dim); no dropout, no residual).  mask: one byte per element, NULL = no dropout (eval, or p == 0); the forward draws it from a
  * counter hash of (seed, element index).  dim: multiple of 8, <= 2048; tensors contiguous, 16-byte aligned. */
+#define CM_SEED_EPOCH_MUL 0x9E3779B97F4A7C15ull
 typedef struct cm_ffn_elem_args {
     int64_t rows;
     int32_t dim, io_dtype, act, dy_f32;      /* dy_f32: backward's dy is fp32 although io_dtype is bf16 (the residual stream)   */
@@ -413,6 +414,9 @@ typedef struct cm_ffn_elem_args {
                                                  training forward of cm_ffn_fused fed to its second GEMM                            */
     int32_t overwrite;                        /* 1: dbias is written, not accumulated into (no memset in front of the call)        */
     int32_t reserved0;
+    const uint64_t *seed_epoch;               /* optional DEVICE word: the stream's seed is seed + *seed_epoch * CM_SEED_EPOCH_MUL
+                                                 (mod 2^64), read when the kernel runs -- a captured hipGraph whose first node
+                                                 advances the word draws fresh decisions at every replay                            */
 } cm_ffn_elem_args;
 
 int64_t cm_bias_act_dropout_bwd_workspace_floats(int64_t rows, int32_t dim);
@@ -846,6 +850,7 @@ typedef struct cm_ffn_args {
                                            1: in cm_ffn_pack_weights32's (32 x 16 tiles, v_mfma_f32_32x32x16_bf16; inference forward only) */
     int32_t tokens;                     /* layout 1: tokens per workgroup, 0 / 64 or 32 (32: for launches of fewer than ~400 64-token
                                            workgroups, which leave CUs idle) */
+    const uint64_t *seed_epoch;         /* optional device word added into seed1 / seed2 (cm_ffn_elem_args.seed_epoch)       */
 } cm_ffn_args;
 
 int cm_ffn_fused(const cm_ffn_args *args);
@@ -874,6 +879,7 @@ typedef struct cm_ffn_bwd_args {
     int64_t workspace_floats;
     void *stream;
     float *db1_part, *db2_part;         /* internal (set by the library)                                                    */
+    const uint64_t *seed_epoch;         /* the forward's (cm_ffn_args.seed_epoch): same device word, same value at run time */
 } cm_ffn_bwd_args;
 
 int64_t cm_ffn_bwd_workspace_floats(int32_t rows, int32_t hidden);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(_HERE, "lib", "libconma
 
 CM_F32, CM_BF16, CM_F16 = 0, 1, 2
 CM_SCAN_CHUNK = 64
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 i32, i64, vp, fp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -90,6 +90,7 @@ class FfnElemArgs(C.Structure):
         ("rows", i64), ("dim", i32), ("io_dtype", i32), ("act", i32), ("dy_f32", i32),
         ("a", vp), ("bias", fp), ("res", fp), ("y", vp), ("mask", vp), ("dy", vp), ("da", vp), ("dbias", fp), ("dbias_part", fp),
         ("p", C.c_float), ("alpha", C.c_float), ("seed", C.c_uint64), ("stream", vp), ("act_out", vp), ("overwrite", i32), ("reserved0", i32),
+        ("seed_epoch", vp),
     ]
 
 
@@ -257,7 +258,7 @@ class FfnArgs(C.Structure):
         ("add_scale", C.c_float), ("alpha", C.c_float), ("pre_eps", C.c_float), ("n1_eps", C.c_float), ("n2_eps", C.c_float),
         ("proj_dim", i32), ("stream", vp), ("proj_w", vp), ("proj_b", fp), ("proj_out", vp),
         ("pre_out", vp), ("xn_out", vp), ("p1", C.c_float), ("p2", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
-        ("stats_out", fp), ("layout", i32), ("tokens", i32),
+        ("stats_out", fp), ("layout", i32), ("tokens", i32), ("seed_epoch", vp),
     ]
 
 
@@ -266,7 +267,7 @@ class FfnBwdArgs(C.Structure):
         ("rows", i32), ("dim", i32), ("hidden", i32), ("reserved0", i32), ("dout", fp), ("w2t", vp), ("w1t", vp), ("pre", vp),
         ("da2", vp), ("da1", vp), ("act", vp), ("dh", vp), ("db1", fp), ("db2", fp),
         ("alpha", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("reserved1", C.c_float), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
-        ("workspace", fp), ("workspace_floats", i64), ("stream", vp), ("db1_part", fp), ("db2_part", fp),
+        ("workspace", fp), ("workspace_floats", i64), ("stream", vp), ("db1_part", fp), ("db2_part", fp), ("seed_epoch", vp),
     ]
 
 

@@ -88,8 +88,12 @@ class ConMambaASR(nn.Module):
         first training batches, train_CTC.py:287; benchmarks / parity runs on random-init models call this once)."""
         self.normalize.update_statistics(self.compute_features(wavs), wav_lens)
 
-    def encode(self, wavs, wav_lens, epoch=0, augment=None):
-        """wav (B, samples) -> encoder output (B, ceil(T/4), d_model): the path the headline metric times."""
+    def encode(self, wavs, wav_lens, epoch=0, augment=None, feats=None):
+        """wav (B, samples) -> encoder output (B, ceil(T/4), d_model): the path the headline metric times.
+        ``feats``: features() of the batch computed by the caller (a graphed training step keeps Fbank, the running
+        normalisation statistics and the host-drawn augmentation outside its hipGraph, brain.Brain.graph_prologue)."""
+        if feats is not None:
+            return self.Transformer.encode(self.CNN(feats), wav_lens)
         if (not torch.is_grad_enabled()) and (not self.training) and wavs.is_cuda and augment is None \
                 and self.normalize.count > 0:
             from . import fused
@@ -98,16 +102,16 @@ class ConMambaASR(nn.Module):
         src = self.CNN(self.features(wavs, wav_lens, epoch, augment))
         return self.Transformer.encode(src, wav_lens)
 
-    def forward_ctc(self, wavs, wav_lens, epoch=0, augment=None):
+    def forward_ctc(self, wavs, wav_lens, epoch=0, augment=None, feats=None):
         """-> log-probabilities (B, T', vocab), train_CTC.py:296-302."""
-        enc = self.encode(wavs, wav_lens, epoch, augment)
+        enc = self.encode(wavs, wav_lens, epoch, augment, feats=feats)
         return torch.log_softmax(self.ctc_lin(enc), dim=-1)
 
-    def forward_s2s(self, wavs, wav_lens, tokens_bos, epoch=0, augment=None, pad_idx=0):
+    def forward_s2s(self, wavs, wav_lens, tokens_bos, epoch=0, augment=None, pad_idx=0, feats=None):
         """train_S2S.py:285-320: features -> CNN -> Transformer(src, <bos> tokens) -> (p_ctc over encoder steps,
         p_seq over decoder steps), both log-probabilities."""
         assert self.cfg.num_decoder_layers > 0, "forward_s2s needs a decoder (S2S configuration)"
-        src = self.CNN(self.features(wavs, wav_lens, epoch, augment))
+        src = self.CNN(self.features(wavs, wav_lens, epoch, augment) if feats is None else feats)
         enc_out, pred = self.Transformer(src, tokens_bos, wav_lens, pad_idx=pad_idx)
         return torch.log_softmax(self.ctc_lin(enc_out), dim=-1), torch.log_softmax(self.seq_lin(pred), dim=-1)
 

@@ -41,6 +41,11 @@ class Brain:
         self.optimizer = None
         self.reducer: Optional[GradAllReducer] = None
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        # run_opts["graph_steps"] (or CM_GRAPH_TRAIN=1): forward + loss + backward of a micro-batch replayed as one hipGraph
+        # per batch shape (see _fit_batch_graphed)
+        self.graph_steps = bool(run_opts.get("graph_steps", os.environ.get("CM_GRAPH_TRAIN", "0") == "1"))
+        self._graphs = {}                          # batch signature -> None (seen once, ran eagerly) | _GraphedMicroBatch
+        self._graph_pool = None
 
     # ---- hooks to override ---------------------------------------------------------------
     def compute_forward(self, batch, stage):
@@ -86,7 +91,88 @@ class Brain:
             return torch.autocast(self.device.type, dtype=torch.float16)
         return torch.autocast(self.device.type, enabled=False)
 
+    def graph_prologue(self, batch):
+        """Graph mode only: the part of a micro-batch that must stay eager (anything whose launches depend on host-side
+        random draws or update Python state: feature extraction with running statistics, SpecAugment).  Returns the batch
+        compute_forward / compute_objectives receive inside the captured region (tensors of fixed shape per signature)."""
+        return batch
+
+    def _micro_batch(self, batch):
+        """forward + loss + backward of one accumulation micro-batch with the gradients folded into the flat buckets and no
+        exchange: the region a graph captures (the exchange, if any, follows eagerly in fit_batch's tail)."""
+        with self.reducer.no_sync():
+            with self._autocast():
+                outputs = self.compute_forward(batch, Stage.TRAIN)
+                loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+            self.reducer.prepare()
+            (loss / self.grad_accumulation_factor).backward()
+            self.reducer.flush()
+        return outputs, loss
+
+    def _fit_batch_graphed(self, batch):
+        """fit_batch with the micro-batch's device work replayed from a hipGraph (a training micro-batch of the small
+        configurations is launch-bound: ~2,500 kernels, host enqueue time above the GPU's).  Per batch signature (shapes
+        and dtypes after graph_prologue): the first micro-batch runs eagerly (it warms the vendor libraries' lazy state), the
+        second is captured and replayed, later ones copy their tensors into the captured inputs and replay.
+        What makes a replay a fresh training step: weight casts are inside the graph (caches dropped before capture),
+        dropout seeds are offset by a device word the graph's first node increments (ops.SEED_EPOCH), torch's own generator
+        is graph-registered by torch.cuda.graph.  The gradient exchange (world > 1) is NOT captured: it runs after the
+        replay, un-overlapped, through reducer.finish()."""
+        from . import ops
+        if self.reducer is None:
+            raise RuntimeError("graph_steps needs the flat gradient buckets (CM_FLAT_GRADS=1 or a GradAllReducer)")
+        should_step = (self.step + 1) % self.grad_accumulation_factor == 0
+        pro = self.graph_prologue(batch)
+        flat = list(pro) if isinstance(pro, (tuple, list)) else [pro]
+        key = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else ("py", t) for t in flat)
+        if key not in self._graphs:                                        # first sight of this shape: eager
+            self._graphs[key] = None
+            outputs, loss = self._micro_batch(pro)
+        else:
+            g = self._graphs[key]
+            if g is None:
+                if ops.SEED_EPOCH is None:
+                    ops.SEED_EPOCH = torch.zeros(1, dtype=torch.int64, device=self.device)
+                ops.invalidate_caches(self.modules)                        # the casts of the weights belong inside the graph
+                static = [t.clone() if torch.is_tensor(t) else t for t in flat]
+                sbatch = type(pro)(static) if isinstance(pro, (tuple, list)) else static[0]
+                before = set(self.reducer._touched)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=self._graph_pool):
+                    ops.SEED_EPOCH.add_(1)
+                    outputs, loss = self._micro_batch(sbatch)
+                    loss = loss.detach()
+                if self._graph_pool is None:
+                    self._graph_pool = graph.pool()
+                g = self._graphs[key] = SimpleNamespace(graph=graph, static=static, outputs=outputs, loss=loss,
+                                                         touched=set(self.reducer._touched))
+                self.reducer._touched = before                           # capture ran no kernel: nothing was touched yet
+            else:
+                for dst, src in zip(g.static, flat):
+                    if torch.is_tensor(dst):
+                        dst.copy_(src)
+            g.graph.replay()
+            self.reducer._touched |= g.touched
+            outputs, loss = g.outputs, g.loss.clone()
+        self._step_tail(should_step, loss)
+        self.step += 1
+        self.on_fit_batch_end(batch, outputs, loss, should_step)
+        return loss.detach()
+
+    def _step_tail(self, should_step, loss):
+        if not should_step:
+            return
+        self.reducer.finish()
+        norm = self.reducer.clip_grad_norm_(self.max_grad_norm)
+        if torch.isfinite(norm) and torch.isfinite(loss):
+            self.reducer.hide_unused()
+            self.optimizer.step()
+            self.optimizer_step += 1
+        self.reducer.zero_grad()
+
     def fit_batch(self, batch):
+        if self.graph_steps:
+            return self._fit_batch_graphed(batch)
         should_step = (self.step + 1) % self.grad_accumulation_factor == 0
         sync = self.reducer.no_sync() if (self.reducer is not None and not should_step) else _null()
         with sync:

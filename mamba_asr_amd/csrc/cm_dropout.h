@@ -21,6 +21,11 @@ __host__ __device__ __forceinline__ uint32_t cm_drop_thresh(float p) {
 __host__ __device__ __forceinline__ float cm_drop_scale(float p) {
     return 1.0f / (1.0f - (float)cm_drop_thresh(p) * (1.0f / 65536.0f));
 }
+// effective seed of a launch: the caller's seed, plus (optionally) a device word read when the kernel runs, so that a captured
+// hipGraph draws fresh decisions at every replay (cm_ffn_elem_args.seed_epoch); forward and backward of one replay see the same word
+__device__ __forceinline__ uint64_t cm_drop_seed(uint64_t seed, const uint64_t *epoch) {
+    return epoch ? seed + *epoch * 0x9E3779B97F4A7C15ull : seed;
+}
 __device__ __forceinline__ uint32_t cm_drop_base(uint64_t seed, uint64_t group) {
     return cm_hash32((uint32_t)group ^ (uint32_t)seed) + (uint32_t)(group >> 32) * 0x85EBCA6Bu + (uint32_t)(seed >> 32);
 }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] da2 tile (GEMM 1's token operand)
     uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab: dg, then da1 in place (GEMM 2's token operand)
     float *red = reinterpret_cast<float *>(hc + TOK * XS);        // [8][256] db1 partial sums of the slab's row groups
+    const uint64_t seed1 = cm_drop_seed(p.seed1, p.seed_epoch), seed2 = cm_drop_seed(p.seed2, p.seed_epoch);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
             for (int i = 0; i < 4; ++i) {
                 const int col = (l15 + 16 * i) * 4;
                 const int64_t e0 = (int64_t)trow * D + col;
-                const uint32_t keep = drop ? cm_drop_keep4(p.seed2, (uint64_t)e0 >> 3, (int)((e0 >> 2) & 1), th2) : 0xfu;
+                const uint32_t keep = drop ? cm_drop_keep4(seed2, (uint64_t)e0 >> 3, (int)((e0 >> 2) & 1), th2) : 0xfu;
                 const bool live = trow < M;                          // rows past the end: zero gradient (they would enter db2 / dg otherwise)
                 uint2 pk;
                 pk.x = pack2((live && (keep & 1u)) ? v[i].x * sc : 0.f, (live && (keep & 2u)) ? v[i].y * sc : 0.f);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
 #pragma unroll
                 for (int i = 0; i < NPH; ++i) {
                     const uint32_t el = el0 + (uint32_t)((i0 + i) * 8) * (uint32_t)F;
-                    const uint32_t keep = drop1 ? cm_drop_keep8(p.seed1, (uint64_t)(el >> 3), th1) : 0xffu;
+                    const uint32_t keep = drop1 ? cm_drop_keep8(seed1, (uint64_t)(el >> 3), th1) : 0xffu;
                     const uint32_t pw[4] = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]}, gw[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
                     uint32_t ao[4], dv_[4];
 #pragma unroll

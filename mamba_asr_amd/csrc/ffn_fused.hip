@@ -55,6 +55,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {         // one v_c
 template <bool ADD, int VAR = 0, bool PROJ = false, bool TRAIN = false>
 __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
     constexpr int PFK = TRAIN ? 2 : PF;                          // the training variant carries its row-wise pass: a 2-deep ring keeps it at 256 VGPRs
+    const uint64_t seed1 = TRAIN ? cm_drop_seed(p.seed1, p.seed_epoch) : 0, seed2 = TRAIN ? cm_drop_seed(p.seed2, p.seed_epoch) : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *xn = reinterpret_cast<uint16_t *>(smem);            // [TOK][XS] normalised tokens
     uint16_t *hc = xn + TOK * XS;                                 // [TOK][XS] hidden slab
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
                     const uint32_t el = el0 + (uint32_t)((i0 + i) * 8) * (uint32_t)F;
                     if (p.pre_out)                                   // rows past the end fall outside the descriptor
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[i]), rpre, el * 2, 0, 0);
-                    const uint32_t keep = drop ? cm_drop_keep8(p.seed1, (uint64_t)(el >> 3), th1) : 0xffu;
+                    const uint32_t keep = drop ? cm_drop_keep8(seed1, (uint64_t)(el >> 3), th1) : 0xffu;
                     const uint32_t w[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w};
                     uint32_t o[4];
 #pragma unroll
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             if constexpr (TRAIN) {
                 if (p.p2 > 0.f) {                                     // second dropout: on W2 g + b2, in front of the scaled residual add
                     const int64_t e0 = (int64_t)(t0 + th * 64 + nb * 16 + l15) * D + f0 + mb * 16;
-                    const uint32_t keep = cm_drop_keep4(p.seed2, (uint64_t)e0 >> 3, (int)((e0 >> 2) & 1), cm_drop_thresh(p.p2));
+                    const uint32_t keep = cm_drop_keep4(seed2, (uint64_t)e0 >> 3, (int)((e0 >> 2) & 1), cm_drop_thresh(p.p2));
                     const float sc2 = cm_drop_scale(p.p2);
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll

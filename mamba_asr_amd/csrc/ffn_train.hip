@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const cm_ffn_
     ld_vec<AT>(reinterpret_cast<const AT *>(p.a) + e0, a);
     if (p.bias) ld_vec<float>(p.bias + c, bs8);                      // two 16-byte loads (per-element loads: 8 extra vector-memory instructions per thread)
     const bool drop = p.p > 0.f;
+    const uint64_t seed = cm_drop_seed(p.seed, p.seed_epoch);
     const float scale = drop ? cm_drop_scale(p.p) : 1.f;
-    const uint32_t keep8 = drop ? cm_drop_keep8(p.seed, (uint64_t)v, cm_drop_thresh(p.p)) : 0xffu;
+    const uint32_t keep8 = drop ? cm_drop_keep8(seed, (uint64_t)v, cm_drop_thresh(p.p)) : 0xffu;
     uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
     const bool live = tr < rp;
     const int c = tc * 8;
     const bool drop = p.p > 0.f;
+    const uint64_t seed = cm_drop_seed(p.seed, p.seed_epoch);
     const float dscale = drop ? cm_drop_scale(p.p) : 1.f, scale = p.alpha * dscale;
     const uint32_t thresh = cm_drop_thresh(p.p);
     float bs[8], acc[8];
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const cm_ffn_
                     const uint2 m = *reinterpret_cast<const uint2 *>(p.mask + e0);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) keep8 = (keep8 & ~(1u << k)) | ((((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 1u) << k);
-                } else keep8 = cm_drop_keep8(p.seed, (uint64_t)e0 >> 3, thresh);
+                } else keep8 = cm_drop_keep8(seed, (uint64_t)e0 >> 3, thresh);
             }
             float a[8];
             if (p.act == 1) {

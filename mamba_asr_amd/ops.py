@@ -168,6 +168,7 @@ def ffn_bwd_fused(dout, w2t, w1t, pre, alpha, p1, p2, seed1, seed2):
     a.dout, a.w2t, a.w1t, a.pre = _ptr(dout), _ptr(w2t.data), _ptr(w1t.data), _ptr(pre)
     a.da2, a.da1, a.act, a.dh, a.db1, a.db2 = _ptr(da2), _ptr(da1), _ptr(act), _ptr(dh), _ptr(db1), _ptr(db2)
     a.alpha, a.p1, a.p2, a.seed1, a.seed2 = float(alpha), float(p1), float(p2), int(seed1), int(seed2)
+    a.seed_epoch = _seed_epoch_ptr()
     a.workspace, a.workspace_floats, a.stream = _ptr(ws), nws, _stream()
     _launch("cm_ffn_bwd_fused", N.lib().cm_ffn_bwd_fused, a, units=rows)
     return da2, da1, act, dh, db1, db2
@@ -188,7 +189,7 @@ def invalidate_caches(module: torch.nn.Module) -> None:
                     pass
     for m in module.modules():
         m.__dict__.pop("_cm_plist", None)
-        for attr in ("_cm_fused_cache", "_cm_frontend_cache"):
+        for attr in ("_cm_fused_cache", "_cm_frontend_cache", "_cm_rows_derived"):
             if hasattr(m, attr):
                 delattr(m, attr)
 
@@ -566,12 +567,35 @@ def scan_cl_fwd(directions, z=None, delta_softplus=True, time_chunks=None, split
 def _elem_args(rows, dim, io_dtype, act, p, alpha):
     a = N.FfnElemArgs()
     a.rows, a.dim, a.io_dtype, a.act, a.p, a.alpha, a.stream = rows, dim, _DT[io_dtype], int(act), float(p), float(alpha), _stream()
+    a.seed_epoch = _seed_epoch_ptr()
     return a
 
 
 def draw_seed() -> int:
     """64-bit seed for a dropout mask from torch's (seedable) CPU generator: no device synchronisation."""
     return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+# Dropout under hipGraph replay.  A seed drawn on the host is a constant of the captured launch; with SEED_EPOCH set to a
+# one-element int64 DEVICE tensor every dropout kernel adds  *SEED_EPOCH * CM_SEED_EPOCH_MUL  to its seed when it runs
+# (cm_ffn_elem_args.seed_epoch), so a graph whose first node increments the word draws new decisions per replay while the
+# forward and backward kernels of one replay still agree.  None (default): the host seed alone.  graphs.GraphedTrainStep sets it.
+SEED_EPOCH = None
+SEED_EPOCH_MUL = 0x9E3779B97F4A7C15
+
+
+def _seed_epoch_ptr():
+    t = SEED_EPOCH
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise RuntimeError("ops.SEED_EPOCH must be a one-element int64 device tensor")
+    return _ptr(t)
+
+
+def effective_seed(seed: int, epoch: int) -> int:
+    """The seed a kernel uses when the device word holds ``epoch`` (for tests and for reproducing a replay eagerly)."""
+    return (int(seed) + int(epoch) * SEED_EPOCH_MUL) & (2 ** 64 - 1)
 
 
 def bias_act_dropout_fwd(a, bias, act=0, p=0.0, res=None, alpha=1.0, seed=None, store_mask=True):
@@ -1453,6 +1477,7 @@ def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0
         stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
         a.pre_out, a.xn_out, a.stats_out = _ptr(pre), _ptr(xn), _ptr(stats)
         a.p1, a.p2, a.seed1, a.seed2 = float(train[0]), float(train[1]), int(train[2]), int(train[3])
+        a.seed_epoch = _seed_epoch_ptr()
         a.stream = _stream()
         _launch("cm_ffn_fused", N.lib().cm_ffn_fused, a, units=rows)
         return xo, (pre, xn, stats)
