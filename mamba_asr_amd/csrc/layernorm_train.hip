@@ -18,7 +18,8 @@ namespace {
 
 template <int LPR> constexpr int nthreads() { return LPR == 64 ? 256 : 512; }   // 4 or 8 waves (the backward's LDS column sums fit either way)
 constexpr int MAXV = 4;                 // 16-byte column groups per lane
-constexpr int BWD_BLOCKS = 512;         // workgroups of the backward = rows of the partial array
+constexpr int BWD_BLOCKS = 512;         // most workgroups of a backward = rows of the partial array (sizes the workspace)
+constexpr int BWD_BLOCKS_ROWS = 256;    // the narrow-row backward's grid: one workgroup per CU
 
 template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_fwd_kernel(const cm_layern
     }
 }
 
-template <int LPR, typename XT, typename YT>
+template <int LPR, typename XT, typename YT, bool PIPE = true>
 __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layernorm_args p) {
     constexpr int RPW = 64 / LPR, NT = nthreads<LPR>();
     __shared__ float red[NT / 64][2][MAXV * 4 * LPR];             // per-wave column sums (after the in-wave reduction)
@@ -154,11 +155,34 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
         g[i] = on[i] ? *reinterpret_cast<const float4 *>(p.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t r0 = wave * RPW; r0 < p.rows; r0 += nwaves * RPW) {
+    // Everything a row group needs (x, dy, the residual branch's gradient, the statistics) is requested in one go, and the
+    // next group's before this one is worked on: the first version asked for dres only after the row reductions (two dependent
+    // round trips per group) and had nothing in flight while it computed -- 3.4 TB/s on (32000, 256) rows.
+    struct RowIn { float4 x[MAXV], d[MAXV], r[MAXV]; float mean, rstd; };
+    auto request = [&](const int64_t r0, RowIn &in) {
+        const int64_t rc = min(r0 + sub, p.rows - 1);
+        in.mean = p.mean[rc], in.rstd = p.rstd[rc];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            in.x[i] = in.d[i] = in.r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on[i]) {
+                in.x[i] = ld4<XT>(x + rc * dim + 4 * (lr + LPR * i));
+                in.d[i] = ld4<YT>(dy + rc * dim + 4 * (lr + LPR * i));
+                if (p.dres && dx) in.r[i] = *reinterpret_cast<const float4 *>(p.dres + rc * dim + 4 * (lr + LPR * i));
+            }
+        }
+    };
+    const int64_t rstep = nwaves * RPW;
+    RowIn cur, nxt;
+    int64_t r0 = wave * RPW;
+    if (PIPE && r0 < p.rows) request(r0, cur);
+    for (; r0 < p.rows; r0 += rstep) {
+        if constexpr (!PIPE) request(r0, cur);
+        else if (r0 + rstep < p.rows) request(r0 + rstep, nxt);     // wave-uniform
         const int64_t row = r0 + sub;
         const bool ok = row < p.rows;
         const int64_t rc = ok ? row : p.rows - 1;
-        const float mean = p.mean[rc], rstd = p.rstd[rc];
+        const float mean = cur.mean, rstd = cur.rstd;
         const float *mrow = ln_mask_row(p, rc);
         float4 xh[MAXV], gy[MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -167,8 +191,8 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
             float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
             xh[i] = d;
             if (on[i]) {
-                const float4 v = ld4<XT>(x + rc * dim + 4 * (lr + LPR * i));
-                d = ld4<YT>(dy + rc * dim + 4 * (lr + LPR * i));
+                const float4 v = cur.x[i];
+                d = cur.d[i];
                 if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);     // rows past the end add nothing to the column sums
                 xh[i] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
                 if (p.act | (p.chan_mask != nullptr)) d = ln_epilogue_grad(p, d, xh[i], g[i], mrow, mcol[i], 4 * (lr + LPR * i));
@@ -187,14 +211,13 @@ __global__ __launch_bounds__(nthreads<LPR>()) void ln_bwd_kernel(const cm_layern
                 if (on[i]) {
                     float4 o = make_float4(rstd * (gy[i].x - c1 - xh[i].x * c2), rstd * (gy[i].y - c1 - xh[i].y * c2),
                                            rstd * (gy[i].z - c1 - xh[i].z * c2), rstd * (gy[i].w - c1 - xh[i].w * c2));
-                    if (p.dres) {                                  // + the residual branch's gradient (pre-norm block)
-                        const float4 r = *reinterpret_cast<const float4 *>(p.dres + row * dim + 4 * (lr + LPR * i));
-                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
-                    }
+                    const float4 r = cur.r[i];                     // + the residual branch's gradient (pre-norm block), or zeros
+                    o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
                     st4(dx + row * dim + 4 * (lr + LPR * i), o);
                 }
             }
         }
+        if constexpr (PIPE) cur = nxt;
     }
     // column sums: over the row groups of a wave (shuffles), over the waves (LDS), one partial row per workgroup
 #pragma unroll
@@ -469,8 +492,18 @@ template <int LPR, typename XT, typename YT> struct FwdLaunch {
 };
 template <int LPR, typename XT, typename YT> struct BwdLaunch {
     static int run(const cm_layernorm_args &a) {
-        const int nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS);
+        // one workgroup per CU: with two row groups in flight per wave the kernel holds ~200 VGPRs, so only one 8-wave workgroup
+        // fits a CU anyway and 512 workgroups ran as two rounds (profiles/r03/ln_bwd_rows.txt: 25.5 -> 22.9 us, reduce 5.1 -> 4.1)
+        int nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS_ROWS);
         hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
+#ifdef CM_ABLATE
+        if (cm_debug_get() == 50 || cm_debug_get() == 51) nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS);   // A/B: two rounds
+        if (cm_debug_get() == 50) {                                  // A/B: and no cross-iteration prefetch
+            hipLaunchKernelGGL((ln_bwd_kernel<LPR, XT, YT, false>), dim3(nblk), dim3(nthreads<LPR>()), 0, st, a);
+            hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.dim + 31) / 32), dim3(256), 0, st, a.workspace, nblk, a.dim, a.dgamma, a.dbeta);
+            return cm_launch_status("cm_layernorm_bwd");
+        }
+#endif
         hipLaunchKernelGGL((ln_bwd_kernel<LPR, XT, YT>), dim3(nblk), dim3(nthreads<LPR>()), 0, st, a);
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.dim + 31) / 32), dim3(256), 0, st, a.workspace, nblk, a.dim, a.dgamma, a.dbeta);
         return cm_launch_status("cm_layernorm_bwd");
