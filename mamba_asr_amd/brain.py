@@ -44,8 +44,10 @@ class Brain:
         # run_opts["graph_steps"] (or CM_GRAPH_TRAIN=1): forward + loss + backward of a micro-batch replayed as one hipGraph
         # per batch shape (see _fit_batch_graphed)
         self.graph_steps = bool(run_opts.get("graph_steps", os.environ.get("CM_GRAPH_TRAIN", "0") == "1"))
-        self._graphs = {}                          # batch signature -> None (seen once, ran eagerly) | _GraphedMicroBatch
+        self._graphs = {}                          # batch signature -> {"fresh" / "warm": captured micro-batch}
         self._graph_pool = None
+        self._caches_epoch = None                  # _weights_epoch() the in-place weight caches were last refreshed at
+        self._epoch_params = None
 
     # ---- hooks to override ---------------------------------------------------------------
     def compute_forward(self, batch, stage):
@@ -109,49 +111,66 @@ class Brain:
             self.reducer.flush()
         return outputs, loss
 
+    def _weights_epoch(self):
+        """Changes whenever a parameter is written in place (optimizer step, load_state_dict, a checkpoint recovery) or its
+        storage is swapped: the sum of the parameters' version counters and storage pointers."""
+        if self._epoch_params is None:
+            self._epoch_params = list(self.modules.parameters())
+        return sum(p._version + p.data_ptr() for p in self._epoch_params)
+
     def _fit_batch_graphed(self, batch):
         """fit_batch with the micro-batch's device work replayed from a hipGraph (a training micro-batch of the small
         configurations is launch-bound: ~2,500 kernels, host enqueue time above the GPU's).  Per batch signature (shapes
-        and dtypes after graph_prologue): the first micro-batch runs eagerly (it warms the vendor libraries' lazy state), the
-        second is captured and replayed, later ones copy their tensors into the captured inputs and replay.
-        What makes a replay a fresh training step: weight casts are inside the graph (caches dropped before capture),
-        dropout seeds are offset by a device word the graph's first node increments (ops.SEED_EPOCH), torch's own generator
-        is graph-registered by torch.cuda.graph.  The gradient exchange (world > 1) is NOT captured: it runs after the
-        replay, un-overlapped, through reducer.finish()."""
+        and dtypes after graph_prologue): the first micro-batch runs eagerly (it warms the vendor libraries' lazy state and
+        creates the weight caches), later ones copy their tensors into the captured inputs and replay.
+        What makes a replay a fresh training step: dropout seeds are offset by a device word the graph's first node
+        increments (ops.SEED_EPOCH), torch's own generator is graph-registered by torch.cuda.graph, and the weight-derived
+        operands (bf16 copies, packed images, the mixers' derived tensors) live in storage that is refreshed IN PLACE
+        (ops.CACHE_INPLACE).  Two variants are captured per signature: "fresh" contains the kernels that refresh those operands
+        and is replayed for the first micro-batch after an optimizer step; "warm" reads them as they are (the other micro-batches
+        of an accumulation window: 2.5 ms of small kernels fewer per 32 x 40 s micro-batch).
+        The gradient exchange (world > 1) is NOT captured: it runs after the replay, un-overlapped, through reducer.finish()."""
         from . import ops
         if self.reducer is None:
             raise RuntimeError("graph_steps needs the flat gradient buckets (CM_FLAT_GRADS=1 or a GradAllReducer)")
+        ops.CACHE_INPLACE = True
         should_step = (self.step + 1) % self.grad_accumulation_factor == 0
         pro = self.graph_prologue(batch)
         flat = list(pro) if isinstance(pro, (tuple, list)) else [pro]
         key = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else ("py", t) for t in flat)
         if key not in self._graphs:                                        # first sight of this shape: eager
-            self._graphs[key] = None
+            self._graphs[key] = {}
             outputs, loss = self._micro_batch(pro)
+            self._caches_epoch = self._weights_epoch()                     # eager lookups refreshed what was stale
         else:
-            g = self._graphs[key]
+            variant = "warm" if self._caches_epoch == self._weights_epoch() else "fresh"
+            g = self._graphs[key].get(variant)
             if g is None:
                 if ops.SEED_EPOCH is None:
                     ops.SEED_EPOCH = torch.zeros(1, dtype=torch.int64, device=self.device)
-                ops.invalidate_caches(self.modules)                        # the casts of the weights belong inside the graph
                 static = [t.clone() if torch.is_tensor(t) else t for t in flat]
                 sbatch = type(pro)(static) if isinstance(pro, (tuple, list)) else static[0]
                 before = set(self.reducer._touched)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=self._graph_pool):
-                    ops.SEED_EPOCH.add_(1)
-                    outputs, loss = self._micro_batch(sbatch)
-                    loss = loss.detach()
+                with (ops.forced_refresh() if variant == "fresh" else _null()) as log:
+                    with torch.cuda.graph(graph, pool=self._graph_pool):
+                        ops.SEED_EPOCH.add_(1)
+                        outputs, loss = self._micro_batch(sbatch)
+                        loss = loss.detach()
                 if self._graph_pool is None:
                     self._graph_pool = graph.pool()
-                g = self._graphs[key] = SimpleNamespace(graph=graph, static=static, outputs=outputs, loss=loss,
-                                                         touched=set(self.reducer._touched))
+                g = self._graphs[key][variant] = SimpleNamespace(graph=graph, static=static, outputs=outputs, loss=loss,
+                                                                  touched=set(self.reducer._touched),
+                                                                  entries=list(log) if variant == "fresh" else [])
                 self.reducer._touched = before                           # capture ran no kernel: nothing was touched yet
             else:
                 for dst, src in zip(g.static, flat):
                     if torch.is_tensor(dst):
                         dst.copy_(src)
             g.graph.replay()
+            if variant == "fresh":
+                ops.rekey_caches(g.entries)                                # the replay refreshed exactly these entries
+                self._caches_epoch = self._weights_epoch()
             self.reducer._touched |= g.touched
             outputs, loss = g.outputs, g.loss.clone()
         self._step_tail(should_step, loss)

@@ -49,6 +49,7 @@ class _Derived:
 
     def __init__(self, m, sfx, cdt, scale):
         self.key = self.make_key(m, cdt)
+        self.cdt, self.nsfx = cdt, len(sfx)
         E, R = m.d_inner, m.dt_rank
         P = ops.rows_dt_pad(R)
         self.P, self.RW = P, P + 32
@@ -70,6 +71,26 @@ class _Derived:
         # gradient are one GEMM / one batched GEMM for the pair instead of one per direction (the step is host-bound: launches count)
         self.xr_bd = torch.block_diag(*self.xr) if len(sfx) == 2 else None
 
+    def rebuild_(self, m, sfx, cdt, scale):
+        """The same operands from the parameters' current values, written into the tensors this object already holds (their
+        addresses are what a captured hipGraph reads: ops.CACHE_INPLACE)."""
+        E, R, P = m.d_inner, m.dt_rank, self.P
+        self.w_in.copy_(m.in_proj.weight.detach())
+        self.w_out.copy_(m.out_proj.weight.detach() * scale)
+        for i, s in enumerate(sfx):
+            xp, dtp = getattr(m, "x_proj" + s), getattr(m, "dt_proj" + s)
+            self.w_out_cat[:, i * E:(i + 1) * E].copy_(self.w_out)
+            self.xr[i][:R].copy_(xp.weight.detach()[:R])
+            self.xr[i][P:].copy_(xp.weight.detach()[R:])
+            self.dtw[i].copy_(ops.pad_dt_weight(dtp.weight.detach().to(cdt)))
+            self.A[i].copy_(-torch.exp(getattr(m, "A_b_log" if s else "A_log").detach().float()))
+            if self.xr_packed:
+                self.xr_packed[i].repack_(self.xr[i])
+            if self.xr_bd is not None:
+                self.xr_bd[i * self.RW:(i + 1) * self.RW, i * E:(i + 1) * E].copy_(self.xr[i])
+        self.key = self.make_key(m, cdt)
+        return self
+
     @staticmethod
     def make_key(m, cdt):
         # the module's parameter OBJECTS, listed once (Module.parameters() walks the module tree: 3 ms of host time per training step,
@@ -83,9 +104,14 @@ class _Derived:
 
 def _derived(m, sfx, cdt, scale) -> _Derived:
     d = getattr(m, "_cm_rows_derived", None)
-    if d is None or d.key != _Derived.make_key(m, cdt):
+    if d is not None and ops._cache_hit(m, "_cm_rows_derived", d.key == _Derived.make_key(m, cdt)):
+        return d
+    if ops.CACHE_INPLACE and d is not None and d.cdt == cdt and d.nsfx == len(sfx) and d.w_in.device == m.in_proj.weight.device:
+        d.rebuild_(m, sfx, cdt, scale)
+    else:
         d = _Derived(m, sfx, cdt, scale)
         m._cm_rows_derived = d
+    ops._cache_note(m, "_cm_rows_derived")
     return d
 
 

@@ -11,6 +11,8 @@ import ctypes as ct
 from typing import Optional, Tuple
 
 import os
+import contextlib
+
 import torch
 
 from . import _native as N
@@ -43,6 +45,54 @@ def _launch(name: str, fn, args, units: int = 0):
     log.append((name, e0, e1, units))
 
 
+# Weight-derived caches under hipGraph replay (brain.Brain graph_steps).  A captured launch reads a cached tensor by ADDRESS, so the
+# caches must keep their storage for as long as a graph lives and be refreshed in place:
+#   CACHE_INPLACE     a miss that finds an older entry of the same shape / dtype rewrites that entry's tensor instead of allocating
+#   forced_refresh()  context: every entry's FIRST lookup is treated as a miss (while the "fresh" variant of a graph is captured: the
+#                     refresh kernels land in the graph) and (owner, attribute) of every refreshed entry is collected, so that the keys
+#                     of exactly those entries can be brought up to date after a replay did the refresh (rekey_caches) -- Python does
+#                     not see a replay's kernels
+CACHE_INPLACE = False
+_FORCE = None                                     # None, or the set of (id(owner), attribute) already refreshed in this forced pass
+_LOG = None
+
+
+@contextlib.contextmanager
+def forced_refresh():
+    global _FORCE, _LOG
+    old = (_FORCE, _LOG)
+    _FORCE, _LOG = set(), []
+    try:
+        yield _LOG
+    finally:
+        _FORCE, _LOG = old
+
+
+def _cache_hit(owner, attr, key_matches: bool) -> bool:
+    if not key_matches:
+        return False
+    return _FORCE is None or (id(owner), attr) in _FORCE
+
+
+def _cache_note(owner, attr):
+    if _FORCE is not None:
+        _FORCE.add((id(owner), attr))
+        _LOG.append((owner, attr))
+
+
+def rekey_caches(entries) -> None:
+    """entries: what forced_refresh() collected.  Marks each entry as holding the CURRENT version of its parameter(s): call only
+    right after the kernels that refresh exactly these entries ran (a replay of the graph they were captured into)."""
+    for owner, attr in entries:
+        c = getattr(owner, attr, None)
+        if c is None:
+            continue
+        if attr == "_cm_rows_derived":
+            c.key = c.make_key(owner, c.cdt)
+        else:
+            setattr(owner, attr, ((owner._version, owner.data_ptr()), c[1]))
+
+
 def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """p in `dtype`, without autograd, cached on the tensor until it is modified in place (optimizer step, load_state_dict,
     broadcast): the autograd nodes of this package use a weight's bf16 copy in forward AND backward, several times per
@@ -51,11 +101,18 @@ def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         return p.detach()
     c = getattr(p, "_cm_cast", None)
     key = (p._version, p.data_ptr())             # data_ptr: `p.data = ...` swaps storage without bumping _version
-    if c is not None and c[0] == key and c[1].dtype == dtype and c[1].device == p.device:
+    usable = c is not None and c[1].dtype == dtype and c[1].device == p.device
+    if usable and _cache_hit(p, "_cm_cast", c[0] == key):
+        return c[1]
+    if CACHE_INPLACE and usable and c[1].shape == p.shape:
+        c[1].copy_(p.detach())                   # same storage, new values
+        p._cm_cast = (key, c[1])
+        _cache_note(p, "_cm_cast")
         return c[1]
     t = p.detach().to(dtype)
     try:
         p._cm_cast = (key, t)
+        _cache_note(p, "_cm_cast")
     except (AttributeError, RuntimeError):
         pass
     return t
@@ -119,11 +176,18 @@ def pack_cached(p: torch.Tensor) -> "PackedWeight":
     """p (2-D parameter) as a bf16 PackedWeight (cm_ffn_fused's fragment-tiled image), cached like cast_cached."""
     c = getattr(p, "_cm_pack", None)
     key = (p._version, p.data_ptr())
-    if c is not None and c[0] == key and c[1].data.device == p.device:
+    usable = c is not None and c[1].data.device == p.device
+    if usable and _cache_hit(p, "_cm_pack", c[0] == key):
+        return c[1]
+    if CACHE_INPLACE and usable and c[1].shape == tuple(p.shape):
+        c[1].repack_(cast_cached(p, torch.bfloat16))
+        p._cm_pack = (key, c[1])
+        _cache_note(p, "_cm_pack")
         return c[1]
     pw = PackedWeight(cast_cached(p, torch.bfloat16))
     try:
         p._cm_pack = (key, pw)
+        _cache_note(p, "_cm_pack")
     except (AttributeError, RuntimeError):
         pass
     return pw
@@ -133,11 +197,18 @@ def pack_cached_t(p: torch.Tensor) -> "PackedWeight":
     """p^T as a bf16 PackedWeight (the "weights" of cm_ffn_bwd_fused's two GEMMs), cached like cast_cached."""
     c = getattr(p, "_cm_pack_t", None)
     key = (p._version, p.data_ptr())
-    if c is not None and c[0] == key and c[1].data.device == p.device:
+    usable = c is not None and c[1].data.device == p.device
+    if usable and _cache_hit(p, "_cm_pack_t", c[0] == key):
+        return c[1]
+    if CACHE_INPLACE and usable and c[1].shape == tuple(p.shape)[::-1]:
+        c[1].repack_(cast_cached(p, torch.bfloat16).t().contiguous())
+        p._cm_pack_t = (key, c[1])
+        _cache_note(p, "_cm_pack_t")
         return c[1]
     pw = PackedWeight(cast_cached(p, torch.bfloat16).t().contiguous())
     try:
         p._cm_pack_t = (key, pw)
+        _cache_note(p, "_cm_pack_t")
     except (AttributeError, RuntimeError):
         pass
     return pw
@@ -1415,9 +1486,17 @@ class PackedWeight:
         self.shape = tuple(w.shape)
         self.layout = layout
         self.data = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
-        fn = N.lib().cm_ffn_pack_weights if layout == 16 else N.lib().cm_ffn_pack_weights32
+        self.repack_(w)
+
+    def repack_(self, w: torch.Tensor) -> "PackedWeight":
+        """Rewrite the image from a new (rows, cols) bf16 matrix of the same shape, in place (the address a captured graph holds)."""
+        if w.dtype != torch.bfloat16 or tuple(w.shape) != self.shape or w.device != self.data.device:
+            raise RuntimeError("PackedWeight.repack_: expected a bf16 tensor of the packed shape on the image's device")
+        w = w.contiguous()
+        fn = N.lib().cm_ffn_pack_weights if self.layout == 16 else N.lib().cm_ffn_pack_weights32
         rc = fn(_ptr(w), w.shape[0], w.shape[1], _ptr(self.data), _stream())
         N.check(rc, "cm_ffn_pack_weights")
+        return self
 
 
 def ffn_fused(x, pre_norm, w1, b1, w2, b2, alpha=0.5, addend=None, add_scale=1.0, norm1=None, norm2=None,
