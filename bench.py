@@ -216,7 +216,10 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
             dist.barrier()
             torch.cuda.synchronize()
 
-    losses = [brain.fit_batch(batch) for _ in range(max(a.warmup, 3 if a.graph_train else 1))]      # graph mode: eager, capture, first replay
+    # graph mode: the first micro-batch is eager, the second captures the "warm" variant, the first one after an optimizer step the
+    # "fresh" one: both captures belong to warm-up
+    n_warm = max(a.warmup, a.accum + 2 if a.graph_train else 1)
+    losses = [brain.fit_batch(batch) for _ in range(n_warm)]
     fence()
     t0 = time.perf_counter()
     exposed = []
@@ -261,7 +264,7 @@ def run_train(a, cfg, dev, rank, world, use_dist, emit_line=True):
     if rank == 0:
         line = {"metric": f"training audio-frames/sec ({cfg.name}, L={a.frames}, fwd+bwd+AdamW" + (", encoder + Mamba decoder, 0.3 CTC + 0.7 KL)" if s2s else ")"),
                 "value": round(value, 1),
-                "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "unit": "audio-frames/s", "n_gpus": world, "steps": a.steps, "warmup": n_warm,
                 "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"{cfg.name}: {'S2S' if s2s else 'CTC'} training micro-batch, {a.batch} utterances x {a.frames} frames per GPU, "
