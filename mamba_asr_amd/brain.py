@@ -46,6 +46,7 @@ class Brain:
         self.graph_steps = bool(run_opts.get("graph_steps", os.environ.get("CM_GRAPH_TRAIN", "0") == "1"))
         self._graphs = {}                          # batch signature -> {"fresh" / "warm": captured micro-batch}
         self._graph_pool = None
+        self._graph_generation = None              # ops.CACHE_GENERATION when the newest graph was captured
         self._caches_epoch = None                  # _weights_epoch() the in-place weight caches were last refreshed at
         self._epoch_params = None
 
@@ -134,6 +135,11 @@ class Brain:
         if self.reducer is None:
             raise RuntimeError("graph_steps needs the flat gradient buckets (CM_FLAT_GRADS=1 or a GradAllReducer)")
         ops.CACHE_INPLACE = True
+        if self._graph_generation != ops.CACHE_GENERATION and any(self._graphs.values()):
+            # a weight cache got new storage since the last capture (ops.invalidate_caches after a load_state_dict, a cache created by
+            # another code path): the captured launches may read addresses the caches no longer own -- start over
+            self._graphs = {}
+            self._graph_pool = None                                        # the pool dies with its last graph
         should_step = (self.step + 1) % self.grad_accumulation_factor == 0
         pro = self.graph_prologue(batch)
         flat = list(pro) if isinstance(pro, (tuple, list)) else [pro]
@@ -159,6 +165,7 @@ class Brain:
                         loss = loss.detach()
                 if self._graph_pool is None:
                     self._graph_pool = graph.pool()
+                self._graph_generation = ops.CACHE_GENERATION              # entries created inside the capture are this graph's own
                 g = self._graphs[key][variant] = SimpleNamespace(graph=graph, static=static, outputs=outputs, loss=loss,
                                                                   touched=set(self.reducer._touched),
                                                                   entries=list(log) if variant == "fresh" else [])

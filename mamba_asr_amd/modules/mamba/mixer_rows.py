@@ -111,6 +111,7 @@ def _derived(m, sfx, cdt, scale) -> _Derived:
     else:
         d = _Derived(m, sfx, cdt, scale)
         m._cm_rows_derived = d
+        ops._cache_new_storage()
     ops._cache_note(m, "_cm_rows_derived")
     return d
 

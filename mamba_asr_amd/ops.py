@@ -53,6 +53,8 @@ def _launch(name: str, fn, args, units: int = 0):
 #                     of exactly those entries can be brought up to date after a replay did the refresh (rekey_caches) -- Python does
 #                     not see a replay's kernels
 CACHE_INPLACE = False
+CACHE_GENERATION = 0                              # bumped whenever an entry gets NEW storage or entries are dropped: graphs captured
+                                                  # before the bump may hold addresses the caches no longer own (brain drops them)
 _FORCE = None                                     # None, or the set of (id(owner), attribute) already refreshed in this forced pass
 _LOG = None
 
@@ -72,6 +74,11 @@ def _cache_hit(owner, attr, key_matches: bool) -> bool:
     if not key_matches:
         return False
     return _FORCE is None or (id(owner), attr) in _FORCE
+
+
+def _cache_new_storage():
+    global CACHE_GENERATION
+    CACHE_GENERATION += 1
 
 
 def _cache_note(owner, attr):
@@ -112,6 +119,7 @@ def cast_cached(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     t = p.detach().to(dtype)
     try:
         p._cm_cast = (key, t)
+        _cache_new_storage()
         _cache_note(p, "_cm_cast")
     except (AttributeError, RuntimeError):
         pass
@@ -187,6 +195,7 @@ def pack_cached(p: torch.Tensor) -> "PackedWeight":
     pw = PackedWeight(cast_cached(p, torch.bfloat16))
     try:
         p._cm_pack = (key, pw)
+        _cache_new_storage()
         _cache_note(p, "_cm_pack")
     except (AttributeError, RuntimeError):
         pass
@@ -208,6 +217,7 @@ def pack_cached_t(p: torch.Tensor) -> "PackedWeight":
     pw = PackedWeight(cast_cached(p, torch.bfloat16).t().contiguous())
     try:
         p._cm_pack_t = (key, pw)
+        _cache_new_storage()
         _cache_note(p, "_cm_pack_t")
     except (AttributeError, RuntimeError):
         pass
@@ -251,6 +261,7 @@ def invalidate_caches(module: torch.nn.Module) -> None:
     torch.no_grad() on the parameter itself, optimizer steps, load_state_dict and `p.data = new` are seen; writes
     THROUGH ``p.data`` (``p.data.copy_()``, EMA / SWA code, vector_to_parameters) are not -- call this after them.
     load_state_dict calls it by itself (hook installed by asr.ConMambaASR)."""
+    _cache_new_storage()
     for p in module.parameters():
         for attr in ("_cm_pack", "_cm_pack_t", "_cm_cast"):
             if hasattr(p, attr):
