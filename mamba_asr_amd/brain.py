@@ -44,7 +44,10 @@ class Brain:
         # run_opts["graph_steps"] (or CM_GRAPH_TRAIN=1): forward + loss + backward of a micro-batch replayed as one hipGraph
         # per batch shape (see _fit_batch_graphed)
         self.graph_steps = bool(run_opts.get("graph_steps", os.environ.get("CM_GRAPH_TRAIN", "0") == "1"))
-        self._graphs = {}                          # batch signature -> {"fresh" / "warm": captured micro-batch}
+        self._graphs = {}                          # batch signature -> {"fresh" / "warm": captured micro-batch}, least recently used first
+        # graphs pay when batch shapes repeat (fixed-length chunks, a bucketing sampler); a recipe whose every batch has its own
+        # padded length would capture forever: at most this many signatures stay captured, the least recently used one goes
+        self.graph_max_shapes = int(run_opts.get("graph_max_shapes", 16))
         self._graph_pool = None
         self._graph_generation = None              # ops.CACHE_GENERATION when the newest graph was captured
         self._caches_epoch = None                  # _weights_epoch() the in-place weight caches were last refreshed at
@@ -144,7 +147,13 @@ class Brain:
         pro = self.graph_prologue(batch)
         flat = list(pro) if isinstance(pro, (tuple, list)) else [pro]
         key = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else ("py", t) for t in flat)
+        if key in self._graphs:
+            self._graphs[key] = self._graphs.pop(key)                      # most recently used: last
         if key not in self._graphs:                                        # first sight of this shape: eager
+            while len(self._graphs) >= max(self.graph_max_shapes, 1):
+                self._graphs.pop(next(iter(self._graphs)))
+            if not any(self._graphs.values()):
+                self._graph_pool = None                                    # the pool dies with its last graph
             self._graphs[key] = {}
             outputs, loss = self._micro_batch(pro)
             self._caches_epoch = self._weights_epoch()                     # eager lookups refreshed what was stale

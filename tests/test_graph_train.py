@@ -185,3 +185,18 @@ def test_graphed_brain_with_dropout_runs_and_differs_between_replays():
         assert int(ops.SEED_EPOCH.item()) == 4                                # one increment per replay (capture itself runs nothing)
     finally:
         ops.SEED_EPOCH = None
+
+
+def test_graph_signature_cap_evicts_least_recently_used():
+    from mamba_asr_amd import ops
+    batches = _batches()
+    try:
+        brain = _tiny_brain(True, dropout=0.0)
+        brain.graph_max_shapes = 1
+        for i in (0, 0, 0, 1, 1, 0, 0):
+            l1, l2 = float(brain.fit_batch(batches[i])), float(brain.fit_batch(batches[i]))
+            assert l1 == l1 and l2 == l2
+            assert len(brain._graphs) == 1
+        assert brain.optimizer_step == 14
+    finally:
+        ops.SEED_EPOCH = None
