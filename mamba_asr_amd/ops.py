@@ -79,6 +79,9 @@ def _cache_hit(owner, attr, key_matches: bool) -> bool:
 def _cache_new_storage():
     global CACHE_GENERATION
     CACHE_GENERATION += 1
+    if os.environ.get("CM_CACHE_TRACE"):                              # who allocates: one line per bump
+        import traceback
+        print("cache generation", CACHE_GENERATION, " <- ".join(f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-5:-1]), flush=True)
 
 
 def _cache_note(owner, attr):

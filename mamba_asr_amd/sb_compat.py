@@ -92,7 +92,8 @@ class _LinearRowsFn(torch.autograd.Function):
             x = x.to(torch.get_autocast_dtype("cuda"))     # the cast autocast would make inside F.linear, made once: the
         ctx.save_for_backward(x, weight)                    # backward reuses it (and the fp32 input need not stay alive)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        ctx.weight_owner = weight                           # the Parameter OBJECT: saved_tensors hands back a new wrapper, on which
+        return F.linear(x, weight, bias)                    # ops.cast_cached's per-object cache would never hit
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -101,7 +102,15 @@ class _LinearRowsFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             from . import ops
-            dx = torch.matmul(dy, ops.cast_cached(weight, dy.dtype))
+            # the cache lives on a long-lived object: the parameter itself, or -- for a reshaped view of one (the pointwise Conv1d's
+            # weight.squeeze(-1), a new tensor object per call) -- the parameter it is a view of
+            own = ctx.weight_owner
+            base = own._base
+            if base is not None and base.numel() == own.numel() and base.is_contiguous() and own.is_contiguous():
+                w_c = ops.cast_cached(base, dy.dtype).view(own.shape)
+            else:
+                w_c = ops.cast_cached(own, dy.dtype)
+            dx = torch.matmul(dy, w_c)
         if ctx.needs_input_grad[1]:
             if x.dim() == 3 and x.shape[0] > 1:
                 from . import ops

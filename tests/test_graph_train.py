@@ -200,3 +200,52 @@ def test_graph_signature_cap_evicts_least_recently_used():
         assert brain.optimizer_step == 14
     finally:
         ops.SEED_EPOCH = None
+
+
+_CHILD_DIST = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["CM_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["CM_ROOT"], "tests"))
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("CM_PORT", "29541"), RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+from test_graph_train import _tiny_brain, _batches
+from mamba_asr_amd.ddp import GradAllReducer
+batches = _batches()
+order = [0, 0, 0, 0, 1, 1, 0, 1]
+def run(graph, use_dist):
+    brain = _tiny_brain(graph, dropout=0.0, accum=2)
+    if use_dist:
+        brain.reducer.close()
+        params = [p for p in brain.modules.parameters() if p.requires_grad]
+        brain.reducer = GradAllReducer(params, always_exchange=True, broadcast_from=None)
+        assert brain.reducer.active
+    losses = [float(brain.fit_batch(batches[i])) for i in order]
+    return losses, [p.detach().clone() for p in brain.modules.parameters()], brain
+l0, p0, _ = run(False, False)                              # eager, no process group
+dist.init_process_group("nccl", rank=0, world_size=1)
+l1, p1, b1 = run(True, True)                               # graphed micro-batches, RCCL exchange after the replay
+out = {"losses": max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(l0, l1)),
+       "params": max(float((a - b).abs().max()) for a, b in zip(p0, p1)),
+       "captured": sum(len(v) for v in b1._graphs.values()), "steps": b1.optimizer_step, "exchanges": b1.reducer.steps}
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_graphed_brain_under_world1_rccl_group(tmp_path):
+    """graph_steps with an ACTIVE GradAllReducer (world-1 `nccl` group, always_exchange): the captured micro-batch accumulates locally,
+    the exchange runs eagerly behind the replay of every stepping micro-batch -- same losses and parameters as the eager
+    single-process loop.  In a child process (a process group in the pytest process would outlive the test)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child_graph_dist.py"
+    script.write_text(_CHILD_DIST)
+    env = dict(os.environ, CM_ROOT=root, CM_PORT=str(29500 + (os.getpid() + 7) % 400), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    print(out)
+    assert out["losses"] < 2e-3 and out["params"] < 5e-4, out
+    assert out["captured"] >= 3 and out["steps"] == 4 and out["exchanges"] == 4, out
