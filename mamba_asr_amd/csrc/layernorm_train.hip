@@ -19,7 +19,7 @@ namespace {
 template <int LPR> constexpr int nthreads() { return LPR == 64 ? 256 : 512; }   // 4 or 8 waves (the backward's LDS column sums fit either way)
 constexpr int MAXV = 4;                 // 16-byte column groups per lane
 constexpr int BWD_BLOCKS = 512;         // most workgroups of a backward = rows of the partial array (sizes the workspace)
-constexpr int BWD_BLOCKS_ROWS = 256;    // the narrow-row backward's grid: one workgroup per CU
+constexpr int BWD_BLOCKS_ROWS = 256;    // the narrow-row backward's grid: one 8-wave workgroup per CU (two 4-wave ones when a row takes a whole wave)
 
 template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -494,7 +494,7 @@ template <int LPR, typename XT, typename YT> struct BwdLaunch {
     static int run(const cm_layernorm_args &a) {
         // one workgroup per CU: with two row groups in flight per wave the kernel holds ~200 VGPRs, so only one 8-wave workgroup
         // fits a CU anyway and 512 workgroups ran as two rounds (profiles/r03/ln_bwd_rows.txt: 25.5 -> 22.9 us, reduce 5.1 -> 4.1)
-        int nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS_ROWS);
+        int nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS_ROWS * 512 / nthreads<LPR>());   // 8 waves per CU either way
         hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
 #ifdef CM_ABLATE
         if (cm_debug_get() == 50 || cm_debug_get() == 51) nblk = grid_for(a.rows, 64 / LPR, nthreads<LPR>(), BWD_BLOCKS);   // A/B: two rounds
