@@ -168,7 +168,9 @@ class Brain:
                 before = set(self.reducer._touched)
                 graph = torch.cuda.CUDAGraph()
                 with (ops.forced_refresh() if variant == "fresh" else _null()) as log:
-                    with torch.cuda.graph(graph, pool=self._graph_pool):
+                    # thread_local: a process group's watchdog thread polls its events with hipEventQuery, which a capture in the
+                    # default "global" mode turns into an error in THAT thread (and the process dies with it)
+                    with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                         ops.SEED_EPOCH.add_(1)
                         outputs, loss = self._micro_batch(sbatch)
                         loss = loss.detach()

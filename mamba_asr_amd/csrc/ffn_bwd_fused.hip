@@ -240,21 +240,21 @@ __global__ __launch_bounds__(NT, 2) void ffn_bwd_kernel(const cm_ffn_bwd_args p)
     }
 }
 
-// out[col] (= or +=) sum over the workgroups' partial rows, fixed order: 32 columns x 8 row groups per workgroup
-__global__ __launch_bounds__(256) void ffn_bwd_colsum_kernel(const float *__restrict__ part, const int nrow, const int dim, float *__restrict__ out) {
-    __shared__ float red[8][32];
+// out[col] (= or +=) sum over the workgroups' partial rows, fixed order: 32 columns x 32 row groups per workgroup
+__global__ __launch_bounds__(1024) void ffn_bwd_colsum_kernel(const float *__restrict__ part, const int nrow, const int dim, float *__restrict__ out) {
+    __shared__ float red[32][32];           // 32 row groups: 8 left each of the few workgroups walking 250 dependent loads at 32 k rows (14 us)
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float s = 0.f;
     if (col < dim) {
 #pragma unroll 8
-        for (int b = grp; b < nrow; b += 8) s += part[(int64_t)b * dim + col];
+        for (int b = grp; b < nrow; b += 32) s += part[(int64_t)b * dim + col];
     }
     red[grp][threadIdx.x & 31] = s;
     __syncthreads();
     if (grp == 0 && col < dim) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x & 31];
         out[col] = t;
     }
 }
@@ -296,6 +296,6 @@ extern "C" int cm_ffn_bwd_fused(const cm_ffn_bwd_args *args) {
     hipStream_t st = reinterpret_cast<hipStream_t>(a.stream);
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(nwg), dim3(NT), smem, st, a);
     if (int rc = cm_launch_status("cm_ffn_bwd_fused")) return rc;
-    hipLaunchKernelGGL(ffn_bwd_colsum_kernel, dim3((a.hidden + D + 31) / 32), dim3(256), 0, st, a.workspace, nwg, a.hidden + D, a.db1);
+    hipLaunchKernelGGL(ffn_bwd_colsum_kernel, dim3((a.hidden + D + 31) / 32), dim3(1024), 0, st, a.workspace, nwg, a.hidden + D, a.db1);
     return cm_launch_status("cm_ffn_bwd_fused(bias sums)");
 }
