@@ -533,37 +533,44 @@ __global__ __launch_bounds__(256) void rows_bwd_carry_kernel(const cm_scan_cl_bw
 // fixed-order second pass: dxdbl rows = sum over the channel-group workgroups (stored in the I/O dtype); parameter gradients =
 // sum over the batch, ACCUMULATED into the caller's fp32 tensors
 template <typename IO, int DTR>
-__global__ __launch_bounds__(256) void scan_rows_bwd_reduce_kernel(const cm_scan_cl_bwd_args p, const bwd_plan pl) {
-    constexpr int RW = DTR + 32, NP = 16 + DTR + 4;
-    const int64_t rows = (int64_t)p.batch * p.seqlen, nrow = (int64_t)p.ndir * rows * RW, npar = (int64_t)p.ndir * p.dim * NP;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrow + npar; i += (int64_t)gridDim.x * 256) {
-        if (i < nrow) {
-            const int z = (int)(i / (rows * RW));
-            const int64_t j = i - (int64_t)z * rows * RW;            // (b, t, col)
-            const float *src = pl.wsx + (int64_t)z * pl.nx * rows * RW + j;
-            float acc = 0.f;
-            for (int x = 0; x < pl.nx; ++x) acc += src[(int64_t)x * rows * RW];
-            const int col = (int)(j % RW);
-            const int64_t bt = j / RW;
-            const int t = (int)(bt % p.seqlen), b = (int)(bt / p.seqlen);
-            const cm_scan_cl_bwd_dir &d = p.dir[z];
-            cm_elem<IO>::store(reinterpret_cast<IO *>(d.dxdbl) + (int64_t)b * d.dxdbl_bs + (int64_t)t * d.dxdbl_ts + col, acc);
-        } else {
-            const int64_t j = i - nrow;
-            const int z = (int)(j / ((int64_t)p.dim * NP));
-            const int64_t cj = j - (int64_t)z * p.dim * NP;          // (channel, slot)
-            const int c = (int)(cj / NP), slot = (int)(cj % NP);
-            const int64_t nslab = (int64_t)p.batch * pl.chunks;
-            const float *src = pl.wsp + (int64_t)z * nslab * p.dim * NP + cj;
-            float acc = 0.f;
-            for (int64_t b = 0; b < nslab; ++b) acc += src[b * p.dim * NP];
-            const cm_scan_cl_bwd_dir &d = p.dir[z];
-            auto put = [&](float *dst) { *dst = p.overwrite ? acc : *dst + acc; };
-            if (slot < 16) put(d.dA + (int64_t)c * 16 + slot);
-            else if (slot < 16 + DTR) put(d.ddt_weight + (int64_t)c * DTR + slot - 16);
-            else if (slot == 16 + DTR) { if (d.dD) put(d.dD + c); }
-            else if (d.ddelta_bias) put(d.ddelta_bias + c);
-        }
+__global__ __launch_bounds__(256) void scan_rows_bwd_reduce_kernel(const cm_scan_cl_bwd_args p, const bwd_plan pl, const int row_blocks) {
+    constexpr int RW = DTR + 32, NP = 16 + DTR + 4, G = RW / 4;
+    const int64_t rows = (int64_t)p.batch * p.seqlen;
+    if ((int)blockIdx.x < row_blocks) {
+        // dxdbl rows: thread = 4 consecutive columns of one (direction = blockIdx.y, sequence, step): 16-byte loads of the nx partial rows,
+        // one 8- / 16-byte store, 32-bit index arithmetic (the first version summed one float per thread behind four 64-bit divisions: 42 us
+        // for 98 MB at 32 x 1000 x 2)
+        const int z = blockIdx.y;
+        const uint32_t j = blockIdx.x * 256u + threadIdx.x;          // (row, column group) of direction z; rows * G < 2^31 (checked by the host)
+        if (j >= (uint32_t)(rows * G)) return;
+        const uint32_t bt = j / G, cg = j % G;
+        const float *src = pl.wsx + ((int64_t)z * pl.nx * rows + bt) * RW + 4 * cg;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
+        for (int x = 1; x < pl.nx; ++x) acc += *reinterpret_cast<const f32x4 *>(src + (int64_t)x * rows * RW);
+        const uint32_t b = bt / (uint32_t)p.seqlen, t = bt - b * (uint32_t)p.seqlen;
+        const cm_scan_cl_bwd_dir &d = p.dir[z];
+        IO *dst = reinterpret_cast<IO *>(d.dxdbl) + (int64_t)b * d.dxdbl_bs + (int64_t)t * d.dxdbl_ts + 4 * cg;
+        if constexpr (sizeof(IO) == 2) *reinterpret_cast<u32x2 *>(dst) = u32x2{cm_pack_bf16(acc[0], acc[1]), cm_pack_bf16(acc[2], acc[3])};
+        else *reinterpret_cast<f32x4 *>(dst) = acc;
+        return;
+    }
+    if (blockIdx.y != 0) return;
+    // parameter gradients: sum over the (sequence, chunk) slabs
+    const int64_t npar = (int64_t)p.ndir * p.dim * NP;
+    for (int64_t j = (int64_t)(blockIdx.x - row_blocks) * 256 + threadIdx.x; j < npar; j += (int64_t)(gridDim.x - row_blocks) * 256) {
+        const int z = (int)(j / ((int64_t)p.dim * NP));
+        const int64_t cj = j - (int64_t)z * p.dim * NP;              // (channel, slot)
+        const int c = (int)(cj / NP), slot = (int)(cj % NP);
+        const int64_t nslab = (int64_t)p.batch * pl.chunks;
+        const float *src = pl.wsp + (int64_t)z * nslab * p.dim * NP + cj;
+        float acc = 0.f;
+        for (int64_t b = 0; b < nslab; ++b) acc += src[b * p.dim * NP];
+        const cm_scan_cl_bwd_dir &d = p.dir[z];
+        auto put = [&](float *dst) { *dst = p.overwrite ? acc : *dst + acc; };
+        if (slot < 16) put(d.dA + (int64_t)c * 16 + slot);
+        else if (slot < 16 + DTR) put(d.ddt_weight + (int64_t)c * DTR + slot - 16);
+        else if (slot == 16 + DTR) { if (d.dD) put(d.dD + c); }
+        else if (d.ddelta_bias) put(d.ddelta_bias + c);
     }
 }
 
@@ -621,9 +628,11 @@ int launch_bwd(const cm_scan_cl_bwd_args &a) {
     }
     hipLaunchKernelGGL((scan_rows_bwd_kernel<IO, DTR, false>), dim3((unsigned)total), dim3(256), smem, st, a, pl);
     if (int rc = cm_launch_status("cm_scan_cl_bwd")) return rc;
-    const int64_t n = (int64_t)a.ndir * a.batch * a.seqlen * RW + (int64_t)a.ndir * a.dim * NP;
-    const int64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL((scan_rows_bwd_reduce_kernel<IO, DTR>), dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, st, a, pl);
+    const int64_t nrow4 = (int64_t)a.batch * a.seqlen * (RW / 4);            // per direction
+    const int row_blocks = (int)((nrow4 + 255) / 256);
+    const int64_t par_blocks = ((int64_t)a.ndir * a.dim * NP + 255) / 256;
+    hipLaunchKernelGGL((scan_rows_bwd_reduce_kernel<IO, DTR>), dim3((unsigned)(row_blocks + (par_blocks > 1024 ? 1024 : par_blocks)), (unsigned)a.ndir), dim3(256), 0,
+                       st, a, pl, row_blocks);
     return cm_launch_status("cm_scan_cl_bwd(reduce)");
 }
 
@@ -656,14 +665,15 @@ extern "C" int cm_scan_cl_bwd(const cm_scan_cl_bwd_args *args) {
                "scan_cl_bwd: needs a 16-byte aligned workspace of %lld bytes (cm_scan_cl_bwd_workspace_bytes), got %lld", (long long)need,
                (long long)a.workspace_bytes);
     const int P = bwd_dtr(a);
+    CM_REQUIRE((int64_t)a.batch * a.seqlen * ((P + 32) / 4) < ((int64_t)1 << 31), CM_EUNSUPPORTED, "scan_cl_bwd: batch x seqlen too large for the reduce pass's 32-bit row index");
     for (int i = 0; i < a.ndir; ++i) {
         const cm_scan_cl_bwd_dir &d = a.dir[i];
         CM_REQUIRE(d.u && d.xdbl && d.A && d.dt_weight && d.ckpt && d.ypre && d.dout && d.du && d.dz && d.dxdbl && d.dA && d.ddt_weight, CM_EINVAL,
                    "scan_cl_bwd: dir %d has a NULL tensor", i);
         CM_REQUIRE((d.dt_rank == 16 || d.dt_rank == 32) && d.dt_rank == P, CM_EUNSUPPORTED, "scan_cl_bwd: dt_rank (padded) %d: 16, or 32 for every direction", d.dt_rank);
         CM_REQUIRE(P == 16 || a.io_dtype == CM_BF16, CM_EUNSUPPORTED, "scan_cl_bwd: 64-wide x_dbl rows (dt_rank > 16) are built for bf16 I/O only");
-        const int64_t st[] = {d.u_bs, d.u_ts, d.ypre_bs, d.ypre_ts, d.dout_bs, d.dout_ts, d.du_bs, d.du_ts, d.dz_bs, d.dz_ts};
-        bool al = cm_aligned(d.u, 16) && cm_aligned(d.ypre, 16) && cm_aligned(d.dout, 16) && cm_aligned(d.du, 16) && cm_aligned(d.dz, 16) &&
+        const int64_t st[] = {d.u_bs, d.u_ts, d.ypre_bs, d.ypre_ts, d.dout_bs, d.dout_ts, d.du_bs, d.du_ts, d.dz_bs, d.dz_ts, d.dxdbl_bs, d.dxdbl_ts};
+        bool al = cm_aligned(d.dxdbl, 16) && cm_aligned(d.u, 16) && cm_aligned(d.ypre, 16) && cm_aligned(d.dout, 16) && cm_aligned(d.du, 16) && cm_aligned(d.dz, 16) &&
                   cm_aligned(d.xdbl, 16) && d.xdbl_bs % vec == 0 && d.xdbl_ts % vec == 0 && cm_aligned(d.A, 16) && cm_aligned(d.dt_weight, 16) &&
                   cm_aligned(d.ckpt, 16);
         for (int64_t s : st) al = al && s % 4 == 0;
