@@ -316,6 +316,9 @@ typedef struct cm_scan_cl_bwd_args {
     void   *stream;
     void   *workspace;       /* cm_scan_cl_bwd_workspace_bytes(args) bytes, 16-byte aligned  */
     int64_t workspace_bytes;
+    int32_t da_log;          /* 1: dA is the gradient w.r.t. A_log of the reference's A = -exp(A_log) (bimamba.py:116-128), i.e. dA * A,
+                                formed in the reduce pass (one element-wise launch per direction less in the caller)      */
+    int32_t reserved0;
 } cm_scan_cl_bwd_args;
 
 int64_t cm_scan_cl_bwd_workspace_bytes(const cm_scan_cl_bwd_args *args);

@@ -128,7 +128,7 @@ class ScanClBwdArgs(C.Structure):
         ("batch", i32), ("seqlen", i32), ("dim", i32), ("dstate", i32), ("io_dtype", i32), ("ndir", i32),
         ("z", vp), ("z_bs", i64), ("z_ts", i64), ("time_chunks", i32), ("overwrite", i32),
         ("dir", ScanClBwdDir * 2),
-        ("stream", vp), ("workspace", vp), ("workspace_bytes", i64),
+        ("stream", vp), ("workspace", vp), ("workspace_bytes", i64), ("da_log", i32), ("reserved0", i32),
     ]
 
 

@@ -567,7 +567,10 @@ __global__ __launch_bounds__(256) void scan_rows_bwd_reduce_kernel(const cm_scan
         for (int64_t b = 0; b < nslab; ++b) acc += src[b * p.dim * NP];
         const cm_scan_cl_bwd_dir &d = p.dir[z];
         auto put = [&](float *dst) { *dst = p.overwrite ? acc : *dst + acc; };
-        if (slot < 16) put(d.dA + (int64_t)c * 16 + slot);
+        if (slot < 16) {
+            if (p.da_log) acc *= d.A[(int64_t)c * 16 + slot];
+            put(d.dA + (int64_t)c * 16 + slot);
+        }
         else if (slot < 16 + DTR) put(d.ddt_weight + (int64_t)c * DTR + slot - 16);
         else if (slot == 16 + DTR) { if (d.dD) put(d.dD + c); }
         else if (d.ddelta_bias) put(d.ddelta_bias + c);

@@ -212,7 +212,7 @@ class MixerRowsFn(torch.autograd.Function):
                              D=getattr(m, "D_b" if s else "D").detach().float(), delta_bias=dtp.bias.detach().float(), dt_weight=dv.dtw[i],
                              reverse=bool(s), ckpt=cks[i], ypre=pcat[:, :, E * i:E * (i + 1)], dout=dmix, du=ducat[:, :, E * i:E * (i + 1)], dz=dzs[i],
                              dxdbl=dxdbl[:, :, RW * i:RW * (i + 1)]))
-        res = ops.scan_cl_bwd(dirs, z)
+        res = ops.scan_cl_bwd(dirs, z, da_log=True)                                    # dA arrives as the gradient of A_log (= dA * A)
         # x_proj: weight gradient per utterance + sum (K = batch * time GEMMs with a 48-row output fill few workgroups), input
         # gradient added to du in place
         grads = []
@@ -246,7 +246,7 @@ class MixerRowsFn(torch.autograd.Function):
             r = res[i]
             dxw = torch.cat([dxr[i][:R], dxr[i][P:]], dim=0)                            # back to x_proj's (R + 32, E) rows
             grads += [dconv[i][0].reshape(convs[i].weight.shape), dconv[i][1], dxw, r["ddt_weight"][:, :R], r["ddelta_bias"],
-                      r["dA"] * dv.A[i], r["dD"]]
+                      r["dA"], r["dD"]]
         grads += [d_in_w, d_out_w]
         if ln is not None:
             grads += [dln[0], dln[1]]

@@ -880,7 +880,7 @@ def scan_ckpt_shape(batch: int, seqlen: int, dim: int):
     return (batch, 2 * ((seqlen + 15) // 16), dim, 16)
 
 
-def scan_cl_bwd(directions, z, time_chunks=0):
+def scan_cl_bwd(directions, z, time_chunks=0, da_log=False):
     """Channels-last selective scan backward, 1 or 2 directions in one launch (cm_scan_cl_bwd): the gradient of
     scan_cl_fwd's xdbl mode (z and softplus on) including the dt_proj part.
 
@@ -888,7 +888,8 @@ def scan_cl_bwd(directions, z, time_chunks=0):
     zero padded (pad_dt_weight), D, delta_bias (dim), ckpt and ypre as the forward wrote them, dout (batch, seqlen, dim),
     reverse; optional pre-allocated du, dz, dxdbl views.  Returns a list of dicts du, dz (this direction's share), dxdbl
     (I/O dtype, [d dt | dB | dC]), and fp32 dA (dim, 16), ddt_weight (dim, P), dD, ddelta_bias (dim).
-    ``time_chunks``: 0 lets the library cut launches that would leave CUs idle along time, 1 never, n asks for n chunks."""
+    ``time_chunks``: 0 lets the library cut launches that would leave CUs idle along time, 1 never, n asks for n chunks.
+    ``da_log``: dA is returned as the gradient w.r.t. A_log (A = -exp(A_log)): dA * A, formed in the reduce pass."""
     if not 1 <= len(directions) <= 2:
         raise RuntimeError("1 or 2 directions")
     u0 = directions[0]["u"]
@@ -901,6 +902,7 @@ def scan_cl_bwd(directions, z, time_chunks=0):
     a.batch, a.seqlen, a.dim, a.dstate, a.io_dtype, a.ndir = b, l, d, 16, _DT[u0.dtype], len(directions)
     a.z, a.z_bs, a.z_ts = _ptr(z), z.stride(0), z.stride(1)
     a.time_chunks = int(time_chunks)
+    a.da_log = int(bool(da_log))
     keep, outs = [], []
     for i, dd in enumerate(directions):
         u, xdbl, dout, ypre, ck = dd["u"], dd["xdbl"], dd["dout"], dd["ypre"], dd["ckpt"]
