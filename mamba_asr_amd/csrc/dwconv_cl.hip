@@ -120,12 +120,20 @@ template <typename IO> __device__ __forceinline__ void st_pair(IO *dst, v2f v) {
 // rows [t_first, t_first + ROWS2) x channels [c0, c0 + CB) of src -> tile (zero outside the sequence / past dim)
 template <typename IO>
 __device__ __forceinline__ void stage_tile(unsigned char *tile, const IO *src, int64_t ts, int t_first, int T, int c0, int D) {
-    constexpr int VEC = cm_elem<IO>::kVec, CPR = CB / VEC;
-    for (int i = threadIdx.x; i < ROWS2 * CPR; i += 256) {
-        const int r = i / CPR, ch = c0 + (i % CPR) * VEC, t = t_first + r;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (t >= 0 && t < T && ch < D) v = *reinterpret_cast<const uint4 *>(src + (int64_t)t * ts + ch);
-        *reinterpret_cast<uint4 *>(tile + (size_t)i * 16) = v;
+    constexpr int VEC = cm_elem<IO>::kVec, CPR = CB / VEC, NPC = (ROWS2 * CPR + 255) / 256;
+    // every piece of the thread is requested before the first is waited for (as a rolled loop: load, s_waitcnt vmcnt(0), ds_write per
+    // piece -- NPC dependent round trips per tile)
+    uint4 v[NPC];
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int i = threadIdx.x + 256 * k, r = i / CPR, ch = c0 + (i % CPR) * VEC, t = t_first + r;
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < ROWS2 * CPR && t >= 0 && t < T && ch < D) v[k] = *reinterpret_cast<const uint4 *>(src + (int64_t)t * ts + ch);
+    }
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < ROWS2 * CPR) *reinterpret_cast<uint4 *>(tile + (size_t)i * 16) = v[k];
     }
 }
 
@@ -134,7 +142,20 @@ __device__ __forceinline__ void stage_tile(unsigned char *tile, const IO *src, i
 // thread's channel pair, flipped when asked.  Uses the tile region: call before staging, it ends with a barrier.
 __device__ __forceinline__ void load_taps(float *scratch, const float *weight, int c0, int D, int K, int pair, bool flip, v2f (&w)[KMAX]) {
     const int n = min(CB, D - c0) * K;
-    for (int i = threadIdx.x; i < n; i += 256) scratch[i] = weight[(int64_t)c0 * K + i];
+    {
+        constexpr int NW = CB * KMAX / 256;                           // the same for the taps: all requests first
+        float wv[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            wv[k] = i < n ? weight[(int64_t)c0 * K + i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n) scratch[i] = wv[k];
+        }
+    }
     __syncthreads();
     const bool ok = c0 + 2 * pair < D;
 #pragma unroll

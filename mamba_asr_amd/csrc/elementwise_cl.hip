@@ -353,7 +353,26 @@ __global__ __launch_bounds__(256, DV == 4 ? 4 : 2) void dwconv_rows_kernel(const
     const bool pre = p.glu_done != 0;
     const int IW = pre ? D : 2 * D;
     const uint16_t *in = reinterpret_cast<const uint16_t *>(p.in) + (int64_t)b * T * IW;
-    // phase 1: rows t0 - K/2 .. t0 + TT - 1 + K/2 -> LDS, zero outside the sequence ('same' padding)
+    // phase 1: rows t0 - K/2 .. t0 + TT - 1 + K/2 -> LDS, zero outside the sequence ('same' padding).
+    // Already-gated rows (the encoder's call: cm_ln_pw_glu did the GLU): every 16-byte piece of the thread is requested before the
+    // first one is waited for.  As a rolled loop (below, kept for the GLU form) the compiler emitted load -> s_waitcnt vmcnt(0) ->
+    // ds_write per piece: eight dependent round trips per thread, "39 % of the workgroup's life waiting for its rows" in the stamps.
+    constexpr int NCH = NIN * (D / 8), NPC = (NCH + 255) / 256;
+    if (pre) {
+        uint4 v[NPC];
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int idx = tid + 256 * i, r = idx / (D / 8), c = (idx % (D / 8)) * 8;
+            const int t = t0 - K / 2 + r;
+            v[i] = uint4{0u, 0u, 0u, 0u};
+            if (idx < NCH && t >= 0 && t < T) v[i] = *reinterpret_cast<const uint4 *>(in + (int64_t)t * IW + c);
+        }
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int idx = tid + 256 * i, r = idx / (D / 8), c = (idx % (D / 8)) * 8;
+            if (idx < NCH) *reinterpret_cast<uint4 *>(g + r * D + c) = v[i];
+        }
+    } else
     for (int idx = tid; idx < NIN * (D / 8); idx += 256) {
         const int r = idx / (D / 8), c = (idx % (D / 8)) * 8;
         const int t = t0 - K / 2 + r;

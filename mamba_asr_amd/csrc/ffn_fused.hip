@@ -104,7 +104,14 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
 #pragma unroll
     for (int s = 0; s < PFK; ++s) wload(0, s, wq[s], true);
 
-    for (int i = tid; i < p.hidden; i += NT) b1s[i] = p.b1[i];
+    // first bias -> LDS: requested here with 16-byte loads, stored below once the rows have been requested too.  (As the rolled loop
+    // `b1s[i] = p.b1[i]` this was hidden / 256 dependent round trips -- load, s_waitcnt vmcnt(0), ds_write -- in front of the row loads.)
+    float4 b1r[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i4 = (tid + NT * k) * 4;
+        b1r[k] = i4 < p.hidden ? *reinterpret_cast<const float4 *>(p.b1 + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // ---- phase 0: xin = x (+ add_scale * addend); xn = LayerNorm_pre(xin) in bf16.
     // Wave w owns tokens 16w .. 16w+15, four per round: a row of 16 lanes holds one token (16 floats per lane), so the
@@ -128,6 +135,11 @@ __global__ __launch_bounds__(NT, 2) void ffn_fused_kernel(const cm_ffn_args p) {
             const int tok = min(t0 + wv * 16 + rd * 4 + lq, M - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[rd][i] = load_x4(tok, (l15 + 16 * i) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                   // loads return in order: this waits for the bias, not for the rows
+            const int i4 = (tid + NT * k) * 4;
+            if (i4 < p.hidden) *reinterpret_cast<float4 *>(b1s + i4) = b1r[k];
         }
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
