@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, (TT == 16 && NB == 3) ? 4 : 2) void conv_xproj
     // direction: phase 1 9.8 k ticks, phase 2 10.7 k (96 MFMAs = 1.5 k of them: the rest was the wave waiting on its own
     // 48 KB weight stream from L2) -- so the weights of the 32-step build are requested BEFORE phase 1 (96 VGPRs held across
     // it, 232 in all) and phase 2 is MFMAs and fragment reads only.
-    const uint16_t *frag = ut[dir] + l15 * XS + lq * 8;
+    // an OFFSET into the shared array, not ut[dir]: indexing the pointer array with a run-time value loses the LDS address space, the
+    // fragment reads became flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) and every k-step drained the weight ring it was meant to overlap
+    const uint16_t *frag = reinterpret_cast<const uint16_t *>(smem) + dir * (TT * XS) + l15 * XS + lq * 8;
     f32x4 acc[NTL][NB];
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
