@@ -80,6 +80,45 @@ def test_cast_cache_sees_data_swap_and_invalidate():
     torch.testing.assert_close(ops.cast_cached(p, torch.bfloat16).float(), p.detach().to(torch.bfloat16).float())
 
 
+def test_inplace_cache_mode_keeps_storage_and_tracks_generations():
+    """ops.CACHE_INPLACE (what a graphed training loop runs under: captured launches hold the caches' ADDRESSES): a stale entry is
+    refreshed in its own storage; forced_refresh() re-derives every entry once and lists what it refreshed; rekey_caches marks exactly
+    those entries current; CACHE_GENERATION moves only when an entry gets new storage or entries are dropped."""
+    p = torch.nn.Parameter(torch.randn(6, 4))
+    q = torch.nn.Parameter(torch.randn(3, 4))
+    old = ops.CACHE_INPLACE
+    try:
+        ops.CACHE_INPLACE = True
+        g0 = ops.CACHE_GENERATION
+        c1 = ops.cast_cached(p, torch.bfloat16)
+        assert ops.CACHE_GENERATION == g0 + 1                       # first sight: new storage
+        with torch.no_grad():
+            p.mul_(2.0)
+        c2 = ops.cast_cached(p, torch.bfloat16)
+        assert c2 is c1 and ops.CACHE_GENERATION == g0 + 1          # refreshed in place
+        torch.testing.assert_close(c2.float(), p.detach().to(torch.bfloat16).float())
+        ops.cast_cached(q, torch.bfloat16)
+        g1 = ops.CACHE_GENERATION
+        with ops.forced_refresh() as log:
+            assert ops.cast_cached(p, torch.bfloat16) is c1         # current key, refreshed anyway (a capture records the kernel) ...
+            assert ops.cast_cached(p, torch.bfloat16) is c1         # ... once
+        assert [(o is p, a) for o, a in log] == [(True, "_cm_cast")] and ops.CACHE_GENERATION == g1
+        with torch.no_grad():
+            p.add_(1.0)
+            q.add_(1.0)
+        c1.copy_(p.detach())                                        # what a replay of the captured refresh does to p's entry only
+        ops.rekey_caches(log)
+        assert p._cm_cast[0] == (p._version, p.data_ptr())          # p's entry is current again ...
+        assert q._cm_cast[0] != (q._version, q.data_ptr())          # ... q's, which no replay refreshed, still counts as stale
+        torch.testing.assert_close(ops.cast_cached(q, torch.bfloat16).float(), q.detach().to(torch.bfloat16).float())
+        lin = torch.nn.Linear(4, 6)
+        lin.weight = p
+        ops.invalidate_caches(lin)
+        assert ops.CACHE_GENERATION == g1 + 1 and not hasattr(p, "_cm_cast")
+    finally:
+        ops.CACHE_INPLACE = old
+
+
 def test_transformer_asr_rejects_unimplemented_attention_type():
     from mamba_asr_amd.modules.TransformerASR import TransformerASR
     cfg = {"d_state": 16, "expand": 2, "d_conv": 4, "bidirectional": True}
