@@ -167,13 +167,26 @@ class Brain:
                 sbatch = type(pro)(static) if isinstance(pro, (tuple, list)) else static[0]
                 before = set(self.reducer._touched)
                 graph = torch.cuda.CUDAGraph()
-                with (ops.forced_refresh() if variant == "fresh" else _null()) as log:
-                    # thread_local: a process group's watchdog thread polls its events with hipEventQuery, which a capture in the
-                    # default "global" mode turns into an error in THAT thread (and the process dies with it)
-                    with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
-                        ops.SEED_EPOCH.add_(1)
-                        outputs, loss = self._micro_batch(sbatch)
-                        loss = loss.detach()
+                try:
+                    with (ops.forced_refresh() if variant == "fresh" else _null()) as log:
+                        # thread_local: a process group's watchdog thread polls its events with hipEventQuery, which a capture in the
+                        # default "global" mode turns into an error in THAT thread (and the process dies with it)
+                        with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                            ops.SEED_EPOCH.add_(1)
+                            outputs, loss = self._micro_batch(sbatch)
+                            loss = loss.detach()
+                except Exception as exc:                                   # noqa: BLE001 -- whatever the recipe's hooks do that a capture forbids
+                    # (a .item(), a host-side length computation, an allocation outside torch): this loop runs eagerly from here on
+                    import warnings
+                    warnings.warn(f"graph_steps: capturing the micro-batch failed ({type(exc).__name__}: {str(exc)[:300]}); "
+                                  "continuing eagerly (keep host synchronisation out of compute_forward / compute_objectives, or move "
+                                  "it into graph_prologue)")
+                    torch.cuda.synchronize()
+                    self.reducer.discard_pending()
+                    self.reducer._touched = before
+                    ops.invalidate_caches(self.modules)                    # entries created inside the failed capture point into its pool
+                    self.graph_steps, self._graphs, self._graph_pool = False, {}, None
+                    return self.fit_batch(batch)
                 if self._graph_pool is None:
                     self._graph_pool = graph.pool()
                 self._graph_generation = ops.CACHE_GENERATION              # entries created inside the capture are this graph's own

@@ -218,6 +218,15 @@ class GradAllReducer:
             b.attach()
         self._detached = False
 
+    def discard_pending(self):
+        """Forget gradients collected since prepare() without folding them in (a backward that did not happen: an aborted hipGraph
+        capture) and re-attach the bucket views."""
+        for b in self.buckets:
+            b.inc_v, b.inc_g = [], []
+            b.attach(keep_foreign=False)
+            b.reset()
+        self._detached = False
+
     @contextlib.contextmanager
     def no_sync(self):
         """Accumulation micro-batch: gradients stay local (the reference's Brain uses DDP.no_sync the same way)."""

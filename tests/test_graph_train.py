@@ -249,3 +249,33 @@ def test_graphed_brain_under_world1_rccl_group(tmp_path):
     print(out)
     assert out["losses"] < 2e-3 and out["params"] < 5e-4, out
     assert out["captured"] >= 3 and out["steps"] == 4 and out["exchanges"] == 4, out
+
+
+def test_capture_failure_falls_back_to_the_eager_loop():
+    """A recipe hook that synchronises with the host (here: .item() inside compute_objectives) cannot be captured: the loop warns, drops
+    graph mode and carries on eagerly -- same losses as a loop that was eager from the start."""
+    import warnings
+    from mamba_asr_amd import ops
+    batch = _batches()[0]
+    try:
+        runs = []
+        for graph in (False, True):
+            brain = _tiny_brain(graph, dropout=0.0)
+            base = brain.compute_objectives
+
+            def with_sync(pred, b, stage, base=base):
+                loss = base(pred, b, stage)
+                assert loss.item() == loss.item()                  # host synchronisation: illegal while a stream is capturing
+                return loss
+            brain.compute_objectives = with_sync
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                losses = [float(brain.fit_batch(batch)) for _ in range(4)]
+            runs.append((losses, brain, [str(x.message) for x in w]))
+        (l_e, _, _), (l_g, bg, msgs) = runs
+        assert bg.graph_steps is False and any("capturing the micro-batch failed" in m for m in msgs)
+        assert bg.optimizer_step == 4
+        for a, b in zip(l_e, l_g):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l_e, l_g)
+    finally:
+        ops.SEED_EPOCH = None
