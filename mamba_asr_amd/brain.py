@@ -143,6 +143,11 @@ class Brain:
             # another code path): the captured launches may read addresses the caches no longer own -- start over
             self._graphs = {}
             self._graph_pool = None                                        # the pool dies with its last graph
+            self._graph_drops = getattr(self, "_graph_drops", 0) + 1
+            if self._graph_drops == 4:
+                import warnings
+                warnings.warn("graph_steps: the captured micro-batches were dropped four times because a weight cache got new storage; a "
+                              "cache that allocates per step defeats graph mode (CM_CACHE_TRACE=1 prints who allocates)")
         should_step = (self.step + 1) % self.grad_accumulation_factor == 0
         pro = self.graph_prologue(batch)
         flat = list(pro) if isinstance(pro, (tuple, list)) else [pro]
